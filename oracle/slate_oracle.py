@@ -1,0 +1,525 @@
+"""CPU oracle for the SLATE / Slot-Attention pre-training step.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``ocrl_amd/`` may import this file; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do,
+and there only as the checker / the timed CPU baseline, never as the product path.
+
+It is a *functional* PyTorch-CPU fp32 restatement (no ``nn.Module``) of the
+reference's algorithm, written from SURVEY.md Appendix A, over a plain ``dict`` of
+tensors keyed by the reference's ``state_dict`` names.
+Gradients come from torch autograd on this restatement.  Each function cites the
+reference ``file:line`` it follows (paths relative to the reference checkout).
+
+Parity pin: ``tests/golden/make_golden.py`` imports the real reference modules in the
+build container, checks this restatement against them on the
+same weights/noise, and commits the vectors under ``tests/golden/``;
+``tests/test_oracle_golden.py`` re-checks the restatement against those vectors
+everywhere (the reference itself never travels).
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+TINY = float(torch.finfo(torch.float32).tiny)
+
+
+# --------------------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------------------
+def default_cfg(**over):
+    """configs/ocr/slate.yaml:1-35 + configs/dataset/_synthetic_env_base.yaml:7-8."""
+    c = dict(
+        obs_size=64, obs_channels=3, vocab_size=4096, d_model=192, cnn_hidden=64,
+        num_iterations=3, num_slots=5, num_slot_heads=1, slot_size=192, mlp_hidden=192,
+        num_dec_blocks=4, num_dec_heads=4, dropout=0.1, use_bcdec=False,
+        tau_start=1.0, tau_final=0.1, tau_steps=30000, hard=False,
+        lr_half_life=250000, lr_dvae=3e-4, lr_enc=1e-4, lr_dec=3e-4,
+        lr_warmup_steps=30000, clip=0.05,
+    )
+    c.update(over)
+    return SimpleNamespace(**c)
+
+
+# --------------------------------------------------------------------------------------
+# parameter inventory and closed-form test weights
+# --------------------------------------------------------------------------------------
+def param_shapes(cfg):
+    """Ordered (name, shape, group, trainable) list in the reference's
+    ``module.parameters()`` order *within each optimiser group*
+    (ocrs/slate/slate_module.py:94-121, ocrs/slate/slate.py:19-34).
+    group: 0 = dvae, 1 = sa (enc, enc_pos, slotattn, slotproj[, dec]), 2 = tfdec."""
+    C, D, V, d = cfg.cnn_hidden, cfg.slot_size, cfg.vocab_size, cfg.d_model
+    S, ch = cfg.obs_size, cfg.obs_channels
+    T = (S // 4) ** 2
+    H = cfg.mlp_hidden
+    out = []
+
+    def add(name, shape, g, trainable=True):
+        out.append((name, tuple(shape), g, trainable))
+
+    # group 0: dVAE (ocrs/common/models.py:10-37)
+    add("_dvae._encoder.0.m.weight", (64, ch, 4, 4), 0)
+    add("_dvae._encoder.0.m.bias", (64,), 0)
+    for i in range(1, 7):
+        add(f"_dvae._encoder.{i}.m.weight", (64, 64, 1, 1), 0)
+        add(f"_dvae._encoder.{i}.m.bias", (64,), 0)
+    add("_dvae._encoder.7.weight", (V, 64, 1, 1), 0)
+    add("_dvae._encoder.7.bias", (V,), 0)
+    dec = [(0, (64, V, 1, 1)), (1, (64, 64, 3, 3)), (2, (64, 64, 1, 1)), (3, (64, 64, 1, 1)),
+           (4, (256, 64, 1, 1)), (6, (64, 64, 3, 3)), (7, (64, 64, 1, 1)), (8, (64, 64, 1, 1)),
+           (9, (256, 64, 1, 1))]
+    for i, shp in dec:
+        add(f"_dvae._decoder.{i}.m.weight", shp, 0)
+        add(f"_dvae._decoder.{i}.m.bias", (shp[0],), 0)
+    add("_dvae._decoder.11.weight", (ch, 64, 1, 1), 0)
+    add("_dvae._decoder.11.bias", (ch,), 0)
+
+    # group 1: CNN encoder, pos-emb, slot attention, slot projection
+    add("_enc._encoder.0.m.weight", (C, ch, 5, 5), 1)
+    add("_enc._encoder.0.m.bias", (C,), 1)
+    for i in (1, 2):
+        add(f"_enc._encoder.{i}.m.weight", (C, C, 5, 5), 1)
+        add(f"_enc._encoder.{i}.m.bias", (C,), 1)
+    add("_enc._encoder.3.weight", (C, C, 5, 5), 1)
+    add("_enc._encoder.3.bias", (C,), 1)
+    add("_enc_pos.channels_map.weight", (C, 4, 1, 1), 1)
+    add("_enc_pos.channels_map.bias", (C,), 1)
+    add("_slotattn.slot_mu", (1, 1, D), 1)
+    add("_slotattn.slot_log_sigma", (1, 1, D), 1)
+    add("_slotattn.layer_norm.weight", (C,), 1)
+    add("_slotattn.layer_norm.bias", (C,), 1)
+    for i in (0, 2):
+        add(f"_slotattn.mlp.{i}.weight", (C, C), 1)
+        add(f"_slotattn.mlp.{i}.bias", (C,), 1)
+    sa = "_slotattn.slot_attention."
+    add(sa + "norm_inputs.weight", (C,), 1)
+    add(sa + "norm_inputs.bias", (C,), 1)
+    add(sa + "norm_slots.weight", (D,), 1)
+    add(sa + "norm_slots.bias", (D,), 1)
+    add(sa + "norm_mlp.weight", (D,), 1)
+    add(sa + "norm_mlp.bias", (D,), 1)
+    add(sa + "project_q.weight", (D, D), 1)
+    add(sa + "project_k.weight", (D, C), 1)
+    add(sa + "project_v.weight", (D, C), 1)
+    add(sa + "gru.weight_ih", (3 * D, D), 1)
+    add(sa + "gru.weight_hh", (3 * D, D), 1)
+    add(sa + "gru.bias_ih", (3 * D,), 1)
+    add(sa + "gru.bias_hh", (3 * D,), 1)
+    add(sa + "mlp.0.weight", (H, D), 1)
+    add(sa + "mlp.0.bias", (H,), 1)
+    add(sa + "mlp.2.weight", (D, H), 1)
+    add(sa + "mlp.2.bias", (D,), 1)
+    add("_slotproj.weight", (d, D), 1)
+    if cfg.use_bcdec:
+        add("_dec._decoder.0.m.weight", (C, D, 5, 5), 1)
+        add("_dec._decoder.0.m.bias", (C,), 1)
+        for i in (1, 2):
+            add(f"_dec._decoder.{i}.m.weight", (C, C, 5, 5), 1)
+            add(f"_dec._decoder.{i}.m.bias", (C,), 1)
+        add("_dec._decoder.3.weight", (ch + 1, C, 3, 3), 1)
+        add("_dec._decoder.3.bias", (ch + 1,), 1)
+        add("_dec._pos_emb.channels_map.weight", (D, 4, 1, 1), 1)
+        add("_dec._pos_emb.channels_map.bias", (D,), 1)
+
+    # group 2: dictionary, BOS, pos-enc, transformer decoder, output head
+    add("_dict.dictionary.weight", (V, d), 2)
+    add("_bos_token._bos_token", (1, 1, d), 2)
+    add("_z_pos.pe", (1, 1 + T, d), 2)
+    for b in range(cfg.num_dec_blocks):
+        p = f"_tfdec.blocks.{b}."
+        add(p + "self_attn_mask", (T, T), 2, False)  # bool nn.Parameter (transformer.py:151-152)
+        add(p + "self_attn_layer_norm.weight", (d,), 2)
+        add(p + "self_attn_layer_norm.bias", (d,), 2)
+        for q in ("q", "k", "v", "o"):
+            add(p + f"self_attn.proj_{q}.weight", (d, d), 2)
+        add(p + "encoder_decoder_attn_layer_norm.weight", (d,), 2)
+        add(p + "encoder_decoder_attn_layer_norm.bias", (d,), 2)
+        for q in ("q", "k", "v", "o"):
+            add(p + f"encoder_decoder_attn.proj_{q}.weight", (d, d), 2)
+        add(p + "ffn_layer_norm.weight", (d,), 2)
+        add(p + "ffn_layer_norm.bias", (d,), 2)
+        add(p + "ffn.0.weight", (4 * d, d), 2)
+        add(p + "ffn.0.bias", (4 * d,), 2)
+        add(p + "ffn.2.weight", (d, 4 * d), 2)
+        add(p + "ffn.2.bias", (d,), 2)
+    add("_tfdec.layer_norm.weight", (d,), 2)
+    add("_tfdec.layer_norm.bias", (d,), 2)
+    add("_out.weight", (V, d), 2)
+    return out
+
+
+def formula_tensor(name, shape, scale=None):
+    """Deterministic closed-form test weight: numpy MT19937 stream seeded by crc32(name).
+    Stable across machines/versions, so weights never need committing."""
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    n = int(np.prod(shape))
+    if scale is None:
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            scale = math.sqrt(3.0 / max(fan_in, 1))
+        else:
+            scale = 0.1
+    a = rs.uniform(-1.0, 1.0, size=n).astype(np.float32) * np.float32(scale)
+    return torch.from_numpy(a.reshape(shape).copy())
+
+
+def formula_params(cfg):
+    """All parameters by formula.  LayerNorm weights are 1 + small so they are not
+    degenerate; 3-D parameters (slot_mu/log_sigma, bos, pe) use a moderate scale."""
+    P = {}
+    T = (cfg.obs_size // 4) ** 2
+    for name, shape, _, trainable in param_shapes(cfg):
+        if not trainable:
+            P[name] = torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1)
+            continue
+        if "norm" in name and name.endswith(".weight"):
+            P[name] = 1.0 + formula_tensor(name, shape, 0.2)
+        elif name.endswith("slot_log_sigma"):
+            P[name] = formula_tensor(name, shape, 0.3)
+        elif len(shape) == 3:
+            P[name] = formula_tensor(name, shape, 0.5)
+        elif name == "_dict.dictionary.weight":
+            P[name] = formula_tensor(name, shape, 1.0)
+        else:
+            P[name] = formula_tensor(name, shape)
+    return P
+
+
+def position_grid(S):
+    """ocrs/common/utils.py:10-27: (1,4,S,S), channel order [north, south, west, east]."""
+    lin = torch.linspace(0, 1, S)
+    east = lin.view(1, S).expand(S, S)
+    west = torch.linspace(1, 0, S).view(1, S).expand(S, S)
+    south = lin.view(S, 1).expand(S, S)
+    north = torch.linspace(1, 0, S).view(S, 1).expand(S, S)
+    return torch.stack([north, south, west, east], 0).unsqueeze(0).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# schedules (ocrs/common/utils.py:37-65, ocrs/slate/slate.py:56-67, slate_module.py:263-267)
+# --------------------------------------------------------------------------------------
+def cosine_anneal(step, start_value, final_value, start_step, final_step):
+    if step < start_step:
+        return start_value
+    if step >= final_step:
+        return final_value
+    a = 0.5 * (start_value - final_value)
+    b = 0.5 * (start_value + final_value)
+    progress = (step - start_step) / (final_step - start_step)
+    return a * math.cos(math.pi * progress) + b
+
+
+def linear_warmup(step, start_value, final_value, start_step, final_step):
+    if step < start_step:
+        return start_value
+    if step >= final_step:
+        return final_value
+    a = final_value - start_value
+    progress = (step + 1 - start_step) / (final_step - start_step)
+    return a * progress + start_value
+
+
+def schedules(cfg, step):
+    """-> tau, (lr_dvae, lr_enc, lr_dec)."""
+    tau = cosine_anneal(step, cfg.tau_start, cfg.tau_final, 0, cfg.tau_steps)
+    warm = linear_warmup(step, 0, 1, 0, cfg.lr_warmup_steps)
+    decay = math.exp(step / cfg.lr_half_life * math.log(0.5))
+    return tau, (cfg.lr_dvae, decay * warm * cfg.lr_enc, decay * warm * cfg.lr_dec)
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def _drop(x, masks, key, p):
+    """Dropout with an injected keep-mask (float 0/1) — nn.Dropout semantics x*keep/(1-p)."""
+    if masks is None or p == 0.0:
+        return x
+    return x * masks[key] / (1.0 - p)
+
+
+def gumbel_softmax(logits, expo, tau, hard, dim):
+    """ocrs/common/utils.py:75-85 with the Exp(1) draw `expo` injected."""
+    g = -(expo + TINY).log()
+    y = F.softmax((logits + g) / tau, dim)
+    if hard:
+        idx = y.argmax(dim, keepdim=True)
+        y_hard = torch.zeros_like(logits).scatter_(dim, idx, 1.0)
+        return y_hard - y.detach() + y
+    return y
+
+
+def dvae_encode(P, obs):
+    """ocrs/common/models.py:14-23,40: conv4x4/s4+ReLU, 6x conv1x1+ReLU, conv1x1 -> log_softmax(dim=1)."""
+    x = F.relu(F.conv2d(obs, P["_dvae._encoder.0.m.weight"], P["_dvae._encoder.0.m.bias"], stride=4))
+    for i in range(1, 7):
+        x = F.relu(F.conv2d(x, P[f"_dvae._encoder.{i}.m.weight"], P[f"_dvae._encoder.{i}.m.bias"]))
+    x = F.conv2d(x, P["_dvae._encoder.7.weight"], P["_dvae._encoder.7.bias"])
+    return F.log_softmax(x, dim=1)
+
+
+def dvae_decode(P, z):
+    """ocrs/common/models.py:24-37,44-45."""
+    def blk(x, i, pad=0):
+        return F.relu(F.conv2d(x, P[f"_dvae._decoder.{i}.m.weight"], P[f"_dvae._decoder.{i}.m.bias"], padding=pad))
+    x = blk(z, 0)
+    x = blk(x, 1, 1)
+    x = blk(x, 2)
+    x = blk(x, 3)
+    x = F.pixel_shuffle(blk(x, 4), 2)
+    x = blk(x, 6, 1)
+    x = blk(x, 7)
+    x = blk(x, 8)
+    x = F.pixel_shuffle(blk(x, 9), 2)
+    return F.conv2d(x, P["_dvae._decoder.11.weight"], P["_dvae._decoder.11.bias"])
+
+
+def cnn_encode(P, obs, grid=None):
+    """ocrs/common/models.py:96-107 + ocrs/common/utils.py:29-33 -> [B, S*S, C] (slate_module.py:132-133)."""
+    x = obs
+    for i in range(3):
+        x = F.relu(F.conv2d(x, P[f"_enc._encoder.{i}.m.weight"], P[f"_enc._encoder.{i}.m.bias"], padding=2))
+    x = F.conv2d(x, P["_enc._encoder.3.weight"], P["_enc._encoder.3.bias"], padding=2)
+    if grid is None:
+        grid = position_grid(obs.shape[-1])
+    x = x + F.conv2d(grid, P["_enc_pos.channels_map.weight"], P["_enc_pos.channels_map.bias"])
+    return x.permute(0, 2, 3, 1).flatten(1, 2)
+
+
+def slot_attention(P, inputs, slots, num_iterations, heads=1, eps=1e-8, return_all=False):
+    """ocrs/common/slot_attn.py:47-102 (general-heads form)."""
+    pre = "_slotattn.slot_attention."
+    B, N, _ = inputs.shape
+    K, D = slots.shape[1], slots.shape[2]
+    x = F.layer_norm(inputs, inputs.shape[-1:], P[pre + "norm_inputs.weight"], P[pre + "norm_inputs.bias"])
+    k = F.linear(x, P[pre + "project_k.weight"]).view(B, N, heads, -1).transpose(1, 2)
+    v = F.linear(x, P[pre + "project_v.weight"]).view(B, N, heads, -1).transpose(1, 2)
+    k = ((D // heads) ** (-0.5)) * k
+    hist = []
+    attn_vis = None
+    for _ in range(num_iterations):
+        slots_prev = slots
+        s = F.layer_norm(slots, (D,), P[pre + "norm_slots.weight"], P[pre + "norm_slots.bias"])
+        q = F.linear(s, P[pre + "project_q.weight"]).view(B, K, heads, -1).transpose(1, 2)
+        logits = torch.matmul(k, q.transpose(-1, -2))                      # [B,h,N,K]
+        attn = F.softmax(logits.transpose(1, 2).reshape(B, N, heads * K), dim=-1)
+        attn = attn.view(B, N, heads, K).transpose(1, 2)
+        attn_vis = attn.sum(1)
+        attn = attn + eps
+        attn = attn / attn.sum(dim=-2, keepdim=True)
+        upd = torch.matmul(attn.transpose(-1, -2), v).transpose(1, 2).reshape(B, K, -1)
+        # nn.GRUCell (gate order r,z,n)
+        gi = F.linear(upd.reshape(-1, D), P[pre + "gru.weight_ih"], P[pre + "gru.bias_ih"])
+        gh = F.linear(slots_prev.reshape(-1, D), P[pre + "gru.weight_hh"], P[pre + "gru.bias_hh"])
+        i_r, i_z, i_n = gi.chunk(3, 1)
+        h_r, h_z, h_n = gh.chunk(3, 1)
+        r = torch.sigmoid(i_r + h_r)
+        zg = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        h = slots_prev.reshape(-1, D)
+        slots = ((1 - zg) * n + zg * h).view(B, K, D)
+        m = F.layer_norm(slots, (D,), P[pre + "norm_mlp.weight"], P[pre + "norm_mlp.bias"])
+        m = F.linear(F.relu(F.linear(m, P[pre + "mlp.0.weight"], P[pre + "mlp.0.bias"])),
+                     P[pre + "mlp.2.weight"], P[pre + "mlp.2.bias"])
+        slots = slots + m
+        hist.append(slots)
+    if return_all:
+        return slots, attn_vis, hist
+    return slots, attn_vis
+
+
+def slot_encoder(P, feats, slot_noise, cfg):
+    """ocrs/common/slot_attn.py:147-161 with the N(0,1) draw injected."""
+    x = F.layer_norm(feats, feats.shape[-1:], P["_slotattn.layer_norm.weight"], P["_slotattn.layer_norm.bias"])
+    x = F.linear(F.relu(F.linear(x, P["_slotattn.mlp.0.weight"], P["_slotattn.mlp.0.bias"])),
+                 P["_slotattn.mlp.2.weight"], P["_slotattn.mlp.2.bias"])
+    slots0 = P["_slotattn.slot_mu"] + torch.exp(P["_slotattn.slot_log_sigma"]) * slot_noise
+    return slot_attention(P, x, slots0, cfg.num_iterations, cfg.num_slot_heads)
+
+
+def mha(P, pre, q_in, k_in, v_in, heads, causal, masks, mkey, p_drop):
+    """ocrs/common/transformer.py:23-50."""
+    B, T, d = q_in.shape
+    S = k_in.shape[1]
+    q = F.linear(q_in, P[pre + "proj_q.weight"]).view(B, T, heads, -1).transpose(1, 2)
+    k = F.linear(k_in, P[pre + "proj_k.weight"]).view(B, S, heads, -1).transpose(1, 2)
+    v = F.linear(v_in, P[pre + "proj_v.weight"]).view(B, S, heads, -1).transpose(1, 2)
+    q = q * (q.shape[-1] ** (-0.5))
+    attn = torch.matmul(q, k.transpose(-1, -2))
+    if causal:
+        m = torch.triu(torch.ones(T, S, dtype=torch.bool), diagonal=1)
+        attn = attn.masked_fill(m, float("-inf"))
+    attn = F.softmax(attn, dim=-1)
+    attn = _drop(attn, masks, mkey + ".attn", p_drop)
+    out = torch.matmul(attn, v).transpose(1, 2).reshape(B, T, -1)
+    out = F.linear(out, P[pre + "proj_o.weight"])
+    return _drop(out, masks, mkey + ".out", p_drop)
+
+
+def transformer_decoder(P, x, mem, cfg, masks=None, p_drop=0.0):
+    """ocrs/common/transformer.py:167-190,216-226 (block 0 normalises the residual stream itself)."""
+    d = x.shape[-1]
+    h = cfg.num_dec_heads
+    for b in range(cfg.num_dec_blocks):
+        pre = f"_tfdec.blocks.{b}."
+        ln = lambda t, nm: F.layer_norm(t, (d,), P[pre + nm + ".weight"], P[pre + nm + ".bias"])
+        if b == 0:
+            x = ln(x, "self_attn_layer_norm")
+            x = x + mha(P, pre + "self_attn.", x, x, x, h, True, masks, f"blk{b}.self", p_drop)
+        else:
+            y = ln(x, "self_attn_layer_norm")
+            x = x + mha(P, pre + "self_attn.", y, y, y, h, True, masks, f"blk{b}.self", p_drop)
+        y = ln(x, "encoder_decoder_attn_layer_norm")
+        x = x + mha(P, pre + "encoder_decoder_attn.", y, mem, mem, h, False, masks, f"blk{b}.cross", p_drop)
+        y = ln(x, "ffn_layer_norm")
+        y = F.linear(F.relu(F.linear(y, P[pre + "ffn.0.weight"], P[pre + "ffn.0.bias"])),
+                     P[pre + "ffn.2.weight"], P[pre + "ffn.2.bias"])
+        x = x + _drop(y, masks, f"blk{b}.ffn", p_drop)
+    return F.layer_norm(x, (d,), P["_tfdec.layer_norm.weight"], P["_tfdec.layer_norm.bias"])
+
+
+def broadcast_decoder(P, slots, cfg, grid=None):
+    """ocrs/common/models.py:110-141."""
+    B, K, D = slots.shape
+    S = cfg.obs_size
+    if grid is None:
+        grid = position_grid(S)
+    x = slots.reshape(B * K, D, 1, 1).expand(B * K, D, S, S)
+    x = x + F.conv2d(grid, P["_dec._pos_emb.channels_map.weight"], P["_dec._pos_emb.channels_map.bias"])
+    for i in range(3):
+        x = F.relu(F.conv2d(x, P[f"_dec._decoder.{i}.m.weight"], P[f"_dec._decoder.{i}.m.bias"], padding=2))
+    x = F.conv2d(x, P["_dec._decoder.3.weight"], P["_dec._decoder.3.bias"], padding=1)
+    ch = cfg.obs_channels
+    rgb = x[:, :ch].reshape(B, K, ch, S, S)
+    m = x[:, -1:].reshape(B, K, 1, S, S).softmax(dim=1)
+    return (rgb * m).sum(dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# the loss (ocrs/slate/slate_module.py:198-241) and the step (ocrs/base.py:60-74)
+# --------------------------------------------------------------------------------------
+def slate_loss(P, obs, noise, cfg, tau, masks=None, train=True):
+    """noise = dict(z=Exp(1)[B,V,E,E], z_hard=Exp(1)[B,V,E,E], slots=N(0,1)[B,K,D]).
+    masks = None (dropout off) or dict of float keep-masks (see _drop keys).
+    Returns a dict with the loss terms and the intermediates tests compare."""
+    p_drop = cfg.dropout if (train and masks is not None) else 0.0
+    B = obs.shape[0]
+    z_logits = dvae_encode(P, obs)                                   # slate_module.py:125
+    z = gumbel_softmax(z_logits, noise["z"], tau, cfg.hard, 1)
+    z_hard = gumbel_softmax(z_logits, noise["z_hard"], tau, True, 1).detach()   # :127
+    recon = dvae_decode(P, z)                                        # :203
+    dvae_mse = ((obs - recon) ** 2).sum() / B                        # :204
+    feats = cnn_encode(P, obs)                                       # :132-133
+    slots, attn = slot_encoder(P, feats, noise["slots"], cfg)        # :135
+    res = dict(z_logits=z_logits, z=z, recon=recon, dvae_mse=dvae_mse, feats=feats,
+               slots=slots, attn=attn)
+    zh = z_hard.permute(0, 2, 3, 1).flatten(1, 2)                    # [B,T,V]  :141
+    tokens = zh.argmax(-1)
+    res["tokens"] = tokens
+    if cfg.use_bcdec:
+        rec = broadcast_decoder(P, slots, cfg)                       # :218-225
+        mse = ((obs - rec) ** 2).sum() / B
+        res.update(loss=mse, mse=mse, recon_bc=rec)
+        return res
+    emb = F.embedding(tokens, P["_dict.dictionary.weight"])          # :142 (OneHotDictionary :276-280)
+    z_emb = torch.cat([P["_bos_token._bos_token"].expand(B, -1, -1), emb], 1)   # :143-145
+    Tn = z_emb.shape[1]
+    z_emb = _drop(z_emb + P["_z_pos.pe"][:, :Tn], masks, "z_pos", p_drop)       # :146 (transformer.py:66)
+    mem = F.linear(slots, P["_slotproj.weight"])                      # :148
+    dec = transformer_decoder(P, z_emb[:, :-1], mem, cfg, masks, p_drop)        # :149
+    pred = F.linear(dec, P["_out.weight"])                            # :150
+    ce = -(zh * torch.log_softmax(pred, dim=-1)).flatten(1).sum(-1).mean()      # :151-156
+    res.update(loss=dvae_mse + ce, cross_entropy=ce, dec_out=dec)
+    return res
+
+
+def grad_clip_inf(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_(…, max_norm, "inf") as called at ocrs/base.py:65-70.
+    grads: list of tensors (None skipped).  Returns (total_norm, coef)."""
+    gs = [g for g in grads if g is not None]
+    total = torch.stack([g.detach().abs().max() for g in gs]).max()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return total, coef
+
+
+def adam_update(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor step (no weight decay, no amsgrad); t = step count after increment."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** t
+    bc2 = 1 - b2 ** t
+    step_size = lr / bc1
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-step_size)
+
+
+class OracleTrainer:
+    """Functional replica of SLATE.update (ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74)."""
+
+    def __init__(self, cfg, params):
+        self.cfg = cfg
+        self.spec = param_shapes(cfg)
+        self.P = {k: v.clone() for k, v in params.items()}
+        for n, _, _, tr in self.spec:
+            if tr:
+                self.P[n].requires_grad_(True)
+        self.m = {n: torch.zeros_like(self.P[n]) for n, _, _, tr in self.spec if tr}
+        self.v = {n: torch.zeros_like(self.P[n]) for n, _, _, tr in self.spec if tr}
+        self.t = {n: 0 for n, _, _, tr in self.spec if tr}
+
+    def loss_and_grads(self, obs, noise, step, masks=None):
+        tau, _ = schedules(self.cfg, step)
+        for n, _, _, tr in self.spec:
+            if tr:
+                self.P[n].grad = None
+        res = slate_loss(self.P, obs, noise, self.cfg, tau, masks)
+        res["loss"].backward()
+        res["tau"] = tau
+        return res
+
+    def update(self, obs, noise, step, masks=None):
+        res = self.loss_and_grads(obs, noise, step, masks)
+        _, lrs = schedules(self.cfg, step)
+        names = [n for n, _, _, tr in self.spec if tr and self.P[n].grad is not None]
+        total, coef = grad_clip_inf([self.P[n].grad for n in names], self.cfg.clip)
+        grp = {n: g for n, _, g, _ in self.spec}
+        with torch.no_grad():
+            for n in names:
+                g = self.P[n].grad.mul_(coef)
+                self.t[n] += 1
+                adam_update(self.P[n], g, self.m[n], self.v[n], self.t[n], lrs[grp[n]])
+        res["norm"] = total
+        res["lrs"] = lrs
+        return res
+
+
+def make_noise(cfg, B, seed):
+    """Reference draw order: exponential_ z, exponential_ z_hard, normal_ slots."""
+    g = torch.Generator().manual_seed(seed)
+    E = cfg.obs_size // 4
+    z = torch.empty(B, cfg.vocab_size, E, E).exponential_(generator=g)
+    zh = torch.empty(B, cfg.vocab_size, E, E).exponential_(generator=g)
+    s = torch.empty(B, cfg.num_slots, cfg.slot_size).normal_(generator=g)
+    return dict(z=z, z_hard=zh, slots=s)
+
+
+def make_masks(cfg, B, seed, p=None):
+    """Keep-masks for the 21 dropout sites (train mode), keyed as _drop expects."""
+    p = cfg.dropout if p is None else p
+    g = torch.Generator().manual_seed(seed)
+    T = (cfg.obs_size // 4) ** 2
+    d, h, K = cfg.d_model, cfg.num_dec_heads, cfg.num_slots
+    bern = lambda *s: (torch.rand(*s, generator=g) >= p).float()
+    M = {"z_pos": bern(B, T + 1, d)}
+    for b in range(cfg.num_dec_blocks):
+        M[f"blk{b}.self.attn"] = bern(B, h, T, T)
+        M[f"blk{b}.self.out"] = bern(B, T, d)
+        M[f"blk{b}.cross.attn"] = bern(B, h, T, K)
+        M[f"blk{b}.cross.out"] = bern(B, T, d)
+        M[f"blk{b}.ffn"] = bern(B, T, d)
+    return M

@@ -1,0 +1,117 @@
+"""The oracle (oracle/slate_oracle.py) against the golden vectors produced from the real
+reference modules by tests/golden/make_golden.py.  CPU only; runs anywhere."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slate_oracle as O
+
+TINY = dict(obs_size=16, vocab_size=128, d_model=64, slot_size=64, mlp_hidden=64,
+            num_slots=3, num_iterations=2, num_dec_blocks=2)
+
+
+def _summ(t):
+    t = t.detach().double().flatten()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+def _replay(cfg, fx, with_masks):
+    B, seed = int(fx["B"]), int(fx["seed"])
+    g = torch.Generator().manual_seed(seed + 1000)
+    obs = torch.rand(B, cfg.obs_channels, cfg.obs_size, cfg.obs_size, generator=g)
+    tr = O.OracleTrainer(cfg, O.formula_params(cfg))
+    step = 0
+    while f"s{step}.loss" in fx:
+        noise = O.make_noise(cfg, B, seed + step)
+        masks = O.make_masks(cfg, B, seed + 77 + step) if with_masks else None
+        res = tr.update(obs, noise, step, masks)
+        for k in ("loss", "dvae_mse", "cross_entropy", "norm"):
+            assert float(res[k]) == pytest.approx(float(fx[f"s{step}.{k}"]), rel=2e-5), (step, k)
+        assert res["tau"] == pytest.approx(float(fx[f"s{step}.tau"]), rel=1e-6)
+        for i, k in enumerate(("lr_dvae", "lr_enc", "lr_dec")):
+            assert res["lrs"][i] == pytest.approx(float(fx[f"s{step}.{k}"]), rel=1e-6)
+        step += 1
+    return tr, obs, step
+
+
+@pytest.mark.parametrize("tag,over,masks", [
+    ("tiny_eval", TINY, False),
+    ("tiny_train", TINY, True),
+])
+def test_update_matches_reference(golden_dir, tag, over, masks):
+    fx = np.load(os.path.join(golden_dir, f"slate_{tag}.npz"))
+    cfg = O.default_cfg(**over)
+    tr, obs, step = _replay(cfg, fx, masks)
+    names = [str(n) for n in fx["param_names"]]
+    for n, ref in zip(names, fx["param_sums"]):
+        got = _summ(tr.P[n])
+        np.testing.assert_allclose(got[1:], ref[1:], rtol=2e-5, err_msg=n)
+        np.testing.assert_allclose(tr.P[n].detach().flatten()[:16].numpy(), fx["paramhead." + n],
+                                   rtol=1e-4, atol=1e-7, err_msg=n)
+    # forward/backward intermediates at the next step
+    B, seed = int(fx["B"]), int(fx["seed"])
+    noise = O.make_noise(cfg, B, seed + step)
+    tr2 = O.OracleTrainer(cfg, {n: p.detach() for n, p in tr.P.items()})
+    res = tr2.loss_and_grads(obs, noise, step, None)
+    assert np.array_equal(res["tokens"].numpy().astype(np.int32), fx["fwd.tokens"])
+    np.testing.assert_allclose(res["slots"].detach().numpy(), fx["fwd.slots"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res["attn"].detach()[:, :64].numpy(), fx["fwd.attn_head"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(res["attn"].detach().sum(1).numpy(), fx["fwd.attn_sums"], rtol=1e-4)
+    assert float(res["dvae_mse"]) == pytest.approx(float(fx["fwd.dvae_mse"]), rel=2e-5)
+    assert float(res["cross_entropy"]) == pytest.approx(float(fx["fwd.cross_entropy"]), rel=2e-5)
+    gmax = max(float(np.sqrt(s[2])) for s in fx["grad_sums"])
+    for n, ref in zip([str(x) for x in fx["grad_names"]], fx["grad_sums"]):
+        got = _summ(tr2.P[n].grad)
+        assert abs(np.sqrt(got[2]) - np.sqrt(ref[2])) <= 2e-4 * max(np.sqrt(ref[2]), 1e-6 * gmax), n
+        key = "grad." + n
+        if key in fx:
+            ref_g = fx[key]
+            tol = 2e-4 * max(np.abs(ref_g).max(), 1e-6 * gmax)
+            assert np.abs(tr2.P[n].grad.numpy() - ref_g).max() <= tol, n
+
+
+def test_a64_real_config_matches_reference(golden_dir):
+    """Real 64x64 / 6 slots / 3 iters / vocab 4096 configuration (BASELINE configs[0] shape), B=2."""
+    fx = np.load(os.path.join(golden_dir, "slate_a64_eval.npz"))
+    cfg = O.default_cfg(obs_size=64, num_slots=6)
+    tr, obs, step = _replay(cfg, fx, False)
+    for n, ref in zip([str(x) for x in fx["param_names"]], fx["param_sums"]):
+        np.testing.assert_allclose(_summ(tr.P[n])[1:], ref[1:], rtol=2e-5, err_msg=n)
+
+
+def test_bcdec_matches_reference(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "slate_bcdec_tiny.npz"))
+    cfg = O.default_cfg(obs_size=16, vocab_size=128, d_model=64, slot_size=64, mlp_hidden=64,
+                        num_slots=3, num_iterations=2, num_dec_blocks=1, use_bcdec=True)
+    B, seed = 2, 11
+    g = torch.Generator().manual_seed(seed + 1000)
+    obs = torch.rand(B, 3, 16, 16, generator=g)
+    tr = O.OracleTrainer(cfg, O.formula_params(cfg))
+    for step in range(2):
+        res = tr.update(obs, O.make_noise(cfg, B, seed + step), step, None)
+        assert float(res["loss"]) == pytest.approx(float(fx[f"s{step}.loss"]), rel=2e-5)
+        assert float(res["norm"]) == pytest.approx(float(fx[f"s{step}.norm"]), rel=2e-5)
+    for n, ref in zip([str(x) for x in fx["param_names"]], fx["param_sums"]):
+        np.testing.assert_allclose(_summ(tr.P[n])[1:], ref[1:], rtol=2e-5, err_msg=n)
+
+
+def test_param_counts_match_survey():
+    """S=64: 5 388 099 trainable; S=128: 5 535 555; bcdec adds 515 460."""
+    def count(cfg):
+        return sum(int(np.prod(s)) for _, s, _, tr in O.param_shapes(cfg) if tr)
+    assert count(O.default_cfg(obs_size=64)) == 5388099
+    assert count(O.default_cfg(obs_size=128)) == 5535555
+    assert count(O.default_cfg(obs_size=128, use_bcdec=True)) - count(O.default_cfg(obs_size=128)) == 515460
+
+
+def test_schedules():
+    cfg = O.default_cfg()
+    tau, lrs = O.schedules(cfg, 0)
+    assert tau == 1.0 and lrs[0] == 3e-4
+    assert lrs[1] == pytest.approx(1e-4 / 30000)
+    tau, lrs = O.schedules(cfg, 30000)
+    assert tau == pytest.approx(0.1)
+    tau, _ = O.schedules(cfg, 15000)
+    assert tau == pytest.approx(0.55)
