@@ -1,0 +1,107 @@
+/* ocrl_hip — C ABI of the MI355X-native SLATE / Slot-Attention pre-training path.
+ *
+ * The reference (ugadiarov-la-phystech-edu/OCRL) is pure Python and has no native boundary of
+ * its own; each entry point below names the reference function(s) whose arithmetic it replaces.
+ * Conventions: every function returns 0 on success, non-zero on error with a thread-local message
+ * from ocrl_last_error(); nothing throws across the ABI.  All pointers are DEVICE pointers to
+ * fp32 (unless noted), 16-byte aligned, caller-owned; `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  No call synchronises the device unless stated.  One handle per
+ * process per GPU; calls on a handle are not thread-safe.
+ */
+#ifndef OCRL_HIP_H
+#define OCRL_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCRL_ABI_VERSION 1
+
+const char* ocrl_last_error(void);
+int ocrl_abi_version(void);
+
+/* ---- model handle: SLATE_Module + SLATE/Base optimiser (ocrs/slate/slate_module.py:23-121,
+ *      ocrs/slate/slate.py:13-34, ocrs/base.py:8-25) */
+typedef struct ocrl_slate ocrl_slate;
+typedef struct ocrl_slate_config {
+    int obs_size, obs_channels;                 /* env_config.obs_size / obs_channels */
+    int vocab_size, d_model;                    /* ocr_config.dvae.* */
+    int cnn_hidden;                             /* ocr_config.cnn.hidden_size (must be 64) */
+    int num_slots, num_iterations, slot_size, mlp_hidden;   /* ocr_config.slotattr.* */
+    int num_dec_blocks, num_dec_heads;          /* ocr_config.tfdec.* */
+    float dropout;                              /* ocr_config.learning.dropout */
+    int max_batch;                              /* workspace is sized for this many images */
+} ocrl_slate_config;
+
+int ocrl_slate_create(const ocrl_slate_config* cfg, ocrl_slate** out);
+void ocrl_slate_destroy(ocrl_slate* h);
+
+/* Parameter inventory in the reference's state_dict names and optimiser-group order
+ * (slate_module.py:94-121): group 0 dvae, 1 enc/enc_pos/slotattn/slotproj, 2 dict/bos/pos/tfdec/out.
+ * offset/numel are in floats inside the flat buffers handed to ocrl_slate_bind; every tensor
+ * starts 16-byte aligned (gaps are zero and inert). */
+int ocrl_slate_param_count(const ocrl_slate* h);
+int ocrl_slate_param_info(const ocrl_slate* h, int i, char* name, int name_cap, int shape[4], int* ndim,
+                          long long* offset, long long* numel, int* group);
+long long ocrl_slate_flat_size(const ocrl_slate* h);
+long long ocrl_slate_group_begin(const ocrl_slate* h, int group);      /* group in 0..3 (3 = end) */
+size_t ocrl_slate_workspace_bytes(const ocrl_slate* h);
+
+/* Adopt caller-allocated (e.g. torch) flat parameter / gradient / Adam-moment buffers of
+ * ocrl_slate_flat_size() floats and a workspace of ocrl_slate_workspace_bytes() bytes, all
+ * 256-byte aligned.  m/v may be NULL for inference.  Synchronises the device once. */
+int ocrl_slate_bind(ocrl_slate* h, float* params, float* grads, float* adam_m, float* adam_v, void* workspace, size_t workspace_bytes);
+
+/* SLATE_Module.get_loss (slate_module.py:198-241), masks=None path.  obs: [B,3,S,S] NCHW in [0,1].
+ * noise_z / noise_zh: optional injected Exp(1) draws laid out [B,T,V] (the reference's two
+ * torch.empty_like(logits).exponential_() tensors permuted to channel-last, utils.py:77);
+ * noise_slots: optional injected N(0,1) [B,K,D] (slot_attn.py:155).  NULL = draw on device from
+ * `seed`.  train != 0 enables dropout (masks derived from `seed`).  Results: ocrl_slate_metrics. */
+int ocrl_slate_forward(ocrl_slate* h, const float* obs, int B, float tau, int train, unsigned long long seed,
+                       const float* noise_z, const float* noise_zh, const float* noise_slots, void* stream);
+/* loss.backward() of the last forward: fills the flat gradient buffer (overwrites). */
+int ocrl_slate_backward(ocrl_slate* h, void* stream);
+/* SLATE_Module.forward (slate_module.py:181-196): slots [B,K,D] and attention [B,N,K] only. */
+int ocrl_slate_encode(ocrl_slate* h, const float* obs, int B, unsigned long long seed, const float* noise_slots, void* stream);
+/* clip_grad_norm_(params, clip, "inf") + Adam(3 groups).step() (base.py:65-72, slate.py:19-34):
+ * grads are first scaled by grad_scale (1/world_size after an all-reduce sum), clip <= 0 disables
+ * clipping, `step` is the 1-based Adam step count.  metrics[3] receives max|g| before scaling. */
+int ocrl_slate_clip_adam(ocrl_slate* h, const float lr[3], float clip, int step, float grad_scale, void* stream);
+int ocrl_slate_grad_norm(ocrl_slate* h, void* stream);
+/* device float[8]: [0] dvae_mse, [1] cross_entropy, [2] loss, [3] max|grad| */
+float* ocrl_slate_metrics(const ocrl_slate* h);
+/* Named tensors of the last step ("slots" [B,K,D], "attn" [B,N,K], "recon" [B,S,S,4], "tokens"
+ * (int32) [B,T], "zraw"/"z" [B,T,V], "feats" [B,N,64], "dec_out" [B,T,d], "pred", "mem", "emb",
+ * "slots0", "sa_inputs") or any parameter name; count = capacity in elements at max_batch. */
+int ocrl_slate_tensor(const ocrl_slate* h, const char* name, float** ptr, long long* count);
+/* The keep-mask (float 0/1) the kernels used for a dropout site in the last forward; site ids:
+ * 1 = z_pos, 16 + 8*block + {0 self.attn, 1 self.out, 2 cross.attn, 3 cross.out, 4 ffn}. */
+int ocrl_slate_dropout_mask(const ocrl_slate* h, unsigned site, long long n, float* out, void* stream);
+
+/* ---- unit entry points (parity tests of the MFMA kernels)
+ * C[M,N] = alpha * op(A) op(B) (+bias[n]) (relu) (* (mask>0)) (+resid); akc/bkc select storage:
+ * akc=1: A is [M,K] row-major, else [K,M]; bkc=1: B is [N,K] row-major (torch Linear weight), else [K,N].
+ * splitk > 1 needs ws of splitk*M*N floats and ldc == N. */
+int ocrl_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int akc, int bkc,
+              float alpha, const float* bias, int relu, const float* mask, int ldmask, const float* resid, int ldr,
+              int splitk, float* ws, void* stream);
+/* F.conv2d(x, w, b, stride 1, padding ks/2) on NHWC x [B,H,W,cin_pad] (cin_pad = 8 or 64; channels >= cin are
+ * zero) with the reference-layout weight w [64,cin,ks,ks]; y [B,H,W,64] NHWC.  ws: ks*ks*cin_pad*64 floats. */
+int ocrl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int cin, int cin_pad, int ks,
+                    int relu, float* ws, void* stream);
+/* grad wrt input of the same conv (square 64->64 layers): dx = conv_transpose(dy, w) * (mask > 0 if mask). ws: 2*ks*ks*64*64 floats. */
+int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream);
+/* grad wrt weight (reference layout [64,cin,ks,ks]) and bias [64] (may be NULL); ws from ocrl_conv2d_wgrad_ws_floats. */
+size_t ocrl_conv2d_wgrad_ws_floats(int B, int H, int W, int ks, int cin_pad);
+int ocrl_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int B, int H, int W, int cin, int cin_pad, int ks,
+                           float* ws, size_t ws_floats, void* stream);
+/* nn.LayerNorm(F) forward / backward over R rows (F in {64,128,192,256}); dgb = [dgamma | dbeta]. */
+int ocrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long long R, int F, void* stream);
+int ocrl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgb,
+                       long long R, int F, float* ws, size_t ws_floats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

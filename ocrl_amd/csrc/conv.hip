@@ -1,0 +1,300 @@
+// Stride-1 "same" KSxKS convolution, NHWC, fp32 on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// conv_fwd_kernel  — implicit GEMM with the input halo tile resident in LDS:
+//     M = 4x32 output pixels per workgroup (one image row segment per wave), N = 64 output
+//     channels, K = KS*KS*CIN walked tap by tap over the SAME LDS tile (input read once per
+//     tile instead of KS*KS times).  Weights come pre-packed as [tap][CIN/8][COUT][8] so a
+//     wave's B fragment is one fully coalesced 1 KiB global read (L1/L2 resident, 400 KB total).
+//     Also serves as the backward-data kernel: feed dY and the flipped/transposed pack, and
+//     give the previous layer's output as `mask` to fuse the ReLU backward.
+// conv_wgrad_kernel — dW[tap][co][ci] = sum_pixels dY[p][co] * X[p+tap][ci]: pixels are the
+//     MFMA k dimension; grid = (chunks, KS) so one workgroup owns one kernel row (KS taps) and
+//     keeps KS 32x32 accumulators per wave across all its tiles; partial slabs are reduced (and
+//     permuted to the reference [co][ci][ky][kx] layout) by conv_wgrad_reduce_kernel.
+#include "common.h"
+#include "kernels.h"
+
+#define TH 4
+#define TW 32
+
+template <int KS, int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
+    static_assert(COUT == 64, "COUT must be 64");
+    static_assert(CIN % 8 == 0, "CIN must be a multiple of 8");
+    constexpr int P = KS / 2;
+    constexpr int HW_ = TW + KS - 1, HH_ = TH + KS - 1;
+    constexpr int LDH = CIN + 4;
+    constexpr int NCH = CIN / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b = bid;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    // ---- halo tile -> LDS (zero outside the image)
+    {
+        constexpr int F4 = CIN / 4;
+        constexpr int TOTAL = HH_ * HW_ * F4;
+        const float* Xb = p.X + (size_t)b * p.H * p.W * CIN;
+        for (int idx = threadIdx.x; idx < TOTAL; idx += 256) {
+            const int c4 = idx % F4, hp = idx / F4;
+            const int hx = hp % HW_, hy = hp / HW_;
+            const int y = y0 - P + hy, x = x0 - P + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W)
+                v = *reinterpret_cast<const float4*>(Xb + ((size_t)y * p.W + x) * CIN + c4 * 4);
+            *reinterpret_cast<float4*>(smem + hp * LDH + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    const float* wl = p.Wp + li * 8 + 4 * lh;   // lane's slice inside one [COUT][8] block
+    constexpr int NIT = KS * KS * NCH;
+    float4 nb0 = *reinterpret_cast<const float4*>(wl);
+    float4 nb1 = *reinterpret_cast<const float4*>(wl + 32 * 8);
+#pragma unroll 1
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ky = tap / KS, kx = tap % KS;
+        const float* arow = smem + ((wave + ky) * HW_ + li + kx) * LDH + 4 * lh;
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {
+            const int it = tap * NCH + cc;
+            const float4 b0 = nb0, b1 = nb1;
+            if (it + 1 < NIT) {
+                nb0 = *reinterpret_cast<const float4*>(wl + (size_t)(it + 1) * COUT * 8);
+                nb1 = *reinterpret_cast<const float4*>(wl + (size_t)(it + 1) * COUT * 8 + 32 * 8);
+            }
+            const float4 a = *reinterpret_cast<const float4*>(arow + cc * 8);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: bias, relu, + posmap, relu-backward mask
+    const int y = y0 + wave;
+    if (y >= p.H) return;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int co = tn * 32 + li;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (x >= p.W) continue;
+            float v = (tn == 0 ? acc0[r] : acc1[r]) + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            const size_t pix = ((size_t)b * p.H + y) * p.W + x;
+            if (p.posmap) v += p.posmap[((size_t)y * p.W + x) * COUT + co];
+            if (p.mask) v = p.mask[pix * COUT + co] > 0.f ? v : 0.f;
+            p.Y[pix * COUT + co] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int KS, int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
+    static_assert(COUT == 64, "COUT must be 64");
+    static_assert(CIN == 64 || CIN == 8, "CIN must be 64 or 8");
+    constexpr int P = KS / 2;
+    constexpr int HW_ = TW + KS - 1;
+    constexpr int KSPLIT = (CIN == 64) ? 1 : 2;     // CIN=8: waves split the pixel rows instead of ci
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dYs = smem;                     // [TH*TW][COUT]
+    float* Xs = smem + TH * TW * COUT;     // [TH][HW_][CIN]
+
+    const int ky = blockIdx.y;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int coh = (CIN == 64) ? (wave >> 1) : (wave & 1);
+    const int cih = (CIN == 64) ? (wave & 1) : 0;
+    const int ksp = (CIN == 64) ? 0 : (wave >> 1);
+    const int lci = (CIN == 64) ? li : (li < CIN ? li : CIN - 1);   // clamp: columns >= CIN are discarded
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int q = t;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y; q /= tiles_y;
+        const int b = q;
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();   // previous tile fully consumed
+        {   // dY tile
+            constexpr int F4 = COUT / 4;
+            const float* g = p.dY + (size_t)b * p.H * p.W * COUT;
+            for (int idx = threadIdx.x; idx < TH * TW * F4; idx += 256) {
+                const int c4 = idx % F4, pp = idx / F4;
+                const int x = x0 + (pp % TW), y = y0 + (pp / TW);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (y < p.H && x < p.W) v = *reinterpret_cast<const float4*>(g + ((size_t)y * p.W + x) * COUT + c4 * 4);
+                *reinterpret_cast<float4*>(dYs + pp * COUT + c4 * 4) = v;
+            }
+        }
+        {   // X rows shifted by this workgroup's ky
+            constexpr int F4 = CIN / 4;
+            const float* g = p.X + (size_t)b * p.H * p.W * CIN;
+            for (int idx = threadIdx.x; idx < TH * HW_ * F4; idx += 256) {
+                const int c4 = idx % F4, hp = idx / F4;
+                const int x = x0 - P + (hp % HW_), y = y0 + ky - P + (hp / HW_);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (y >= 0 && y < p.H && x >= 0 && x < p.W) v = *reinterpret_cast<const float4*>(g + ((size_t)y * p.W + x) * CIN + c4 * 4);
+                *reinterpret_cast<float4*>(Xs + hp * CIN + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        constexpr int R0N = TH / KSPLIT;
+#pragma unroll 1
+        for (int rr = 0; rr < R0N; ++rr) {
+            const int r = ksp * R0N + rr;
+            const float* ay = dYs + (r * TW + lh) * COUT + coh * 32 + li;
+            const float* bx = Xs + (r * HW_ + lh) * CIN + cih * 32 + lci;
+#pragma unroll 4
+            for (int xx = 0; xx < TW; xx += 2) {
+                const float a = ay[xx * COUT];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const float bb = bx[(xx + kx) * CIN];
+                    acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc[kx], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial slab [slab][ky*KS+kx][co][CIN]
+    const int slab = blockIdx.x * KSPLIT + ksp;
+    float* out = p.part + ((size_t)slab * KS * KS + ky * KS) * COUT * CIN;
+    if (CIN == 64 || li < CIN) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[((size_t)kx * COUT + co) * CIN + cih * 32 + li] = acc[kx][r];
+            }
+    }
+}
+
+// dW[co][ci][ky][kx] (reference layout, cin_real channels) = sum_slabs part[slab][tap][co][ci]
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int nslab,
+                                         int KS, int CIN, int COUT, int cin_real, int accumulate) {
+    const int n = KS * KS * COUT * CIN;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ci = i % CIN, co = (i / CIN) % COUT, tap = i / (CIN * COUT);
+    if (ci >= cin_real) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += part[(size_t)k * n + i];
+    float* d = dW + ((size_t)co * cin_real + ci) * KS * KS + tap;
+    *d = accumulate ? *d + s : s;
+}
+
+// W[co][ci][ky][kx] -> forward pack [tap][CIN/8][COUT][8]   (ci >= cin_real -> 0)
+//                   -> backward-data pack [tap'][COUT/8][cin][8] with tap' = flipped tap (roles of ci/co swapped)
+__global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict__ fwd, float* __restrict__ bwd,
+                                 int KS, int CIN, int COUT, int cin_real) {
+    const int n = KS * KS * CIN * COUT;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // i enumerates the forward pack: [tap][cc][co][e]
+    const int e = i % 8, co = (i / 8) % COUT, cc = (i / (8 * COUT)) % (CIN / 8), tap = i / (8 * COUT * (CIN / 8));
+    const int ci = cc * 8 + e;
+    const float v = ci < cin_real ? W[((size_t)co * cin_real + ci) * KS * KS + tap] : 0.f;
+    fwd[i] = v;
+    if (bwd) {   // only for CIN == cin_real (square layers): bwd[tapf][co/8][ci][co%8]
+        const int tapf = KS * KS - 1 - tap;
+        bwd[(((size_t)tapf * (COUT / 8) + co / 8) * CIN + ci) * 8 + (co % 8)] = v;
+    }
+}
+
+template <int KS, int CIN>
+static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
+    constexpr int smem = (TH + KS - 1) * (TW + KS - 1) * (CIN + 4) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CIN, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int grid = cdiv(a.W, TW) * cdiv(a.H, TH) * a.B;
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, CIN, 64>), dim3(grid), dim3(256), smem, st, a);
+    OCRL_CHECK_LAUNCH("conv_fwd_kernel");
+    return 0;
+}
+
+int conv_fwd_launch(const ConvArgs& a, int KS, int CIN, int COUT, hipStream_t st) {
+    OCRL_REQUIRE(COUT == 64, "conv: COUT must be 64 (got %d)", COUT);
+    OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "conv: empty input");
+    OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.Wp & 15) == 0, "conv: X/Wp must be 16-byte aligned");
+    if (KS == 5 && CIN == 64) return conv_fwd_cfg<5, 64>(a, st);
+    if (KS == 5 && CIN == 8) return conv_fwd_cfg<5, 8>(a, st);
+    if (KS == 3 && CIN == 64) return conv_fwd_cfg<3, 64>(a, st);
+    ocrl_set_error("conv: unsupported KS=%d CIN=%d", KS, CIN);
+    return 1;
+}
+
+template <int KS, int CIN>
+static int conv_wgrad_cfg(const WgradArgs& a, int nchunk, hipStream_t st) {
+    constexpr int smem = (TH * TW * 64 + TH * (TW + KS - 1) * CIN) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<KS, CIN, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, CIN, 64>), dim3(nchunk, KS), dim3(256), smem, st, a);
+    OCRL_CHECK_LAUNCH("conv_wgrad_kernel");
+    return 0;
+}
+
+int conv_wgrad_chunks(int B, int H, int W, int KS) {
+    const int ntiles = cdiv(W, TW) * cdiv(H, TH) * B;
+    int n = (2 * 256 + KS - 1) / KS;
+    return n < ntiles ? n : ntiles;
+}
+size_t conv_wgrad_ws_floats(int B, int H, int W, int KS, int CIN) {
+    const int ks = CIN == 64 ? 1 : 2;
+    return (size_t)conv_wgrad_chunks(B, H, W, KS) * ks * KS * KS * 64 * CIN;
+}
+
+int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st) {
+    OCRL_REQUIRE(COUT == 64, "conv wgrad: COUT must be 64 (got %d)", COUT);
+    const int nchunk = conv_wgrad_chunks(a.B, a.H, a.W, KS);
+    int rc;
+    if (KS == 5 && CIN == 64) rc = conv_wgrad_cfg<5, 64>(a, nchunk, st);
+    else if (KS == 5 && CIN == 8) rc = conv_wgrad_cfg<5, 8>(a, nchunk, st);
+    else if (KS == 3 && CIN == 64) rc = conv_wgrad_cfg<3, 64>(a, nchunk, st);
+    else { ocrl_set_error("conv wgrad: unsupported KS=%d CIN=%d", KS, CIN); return 1; }
+    if (rc) return rc;
+    const int nslab = nchunk * (CIN == 64 ? 1 : 2);
+    const int n = KS * KS * COUT * CIN;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a.part, dW, nslab, KS, CIN, COUT, cin_real, accumulate);
+    OCRL_CHECK_LAUNCH("conv_wgrad_reduce");
+    return 0;
+}
+
+int conv_pack_launch(const float* W, float* fwd, float* bwd, int KS, int CIN, int COUT, int cin_real, hipStream_t st) {
+    OCRL_REQUIRE(bwd == nullptr || (CIN == cin_real && CIN == COUT), "conv pack: backward pack needs a square layer");
+    const int n = KS * KS * CIN * COUT;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, W, fwd, bwd, KS, CIN, COUT, cin_real);
+    OCRL_CHECK_LAUNCH("conv_pack");
+    return 0;
+}

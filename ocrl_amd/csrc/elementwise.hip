@@ -1,0 +1,877 @@
+// Bandwidth-bound helper kernels of the SLATE step (layout changes, LayerNorm, reductions,
+// Gumbel-softmax, cross-entropy, embedding, dropout, causal softmax, cross-attention).
+// All fp32; rows are processed by whole waves / workgroups with coalesced float4 access.
+#include "common.h"
+#include "kernels.h"
+
+#define TINYF 1.17549435e-38f
+
+__device__ inline float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ inline float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = red[0];
+    for (int i = 1; i < nw; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// ------------------------------------------------------------------ layout kernels
+// obs [B,C,H,W] -> out [B,H,W,8] (channels >= C are zero)
+__global__ void nchw_to_nhwc8_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W) {
+    const long long n = (long long)B * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long hw = (long long)H * W;
+    const long long b = i / hw, r = i % hw;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < C ? in[(b * C + c) * hw + r] : 0.f;
+    float4* o = reinterpret_cast<float4*>(out + i * 8);
+    o[0] = make_float4(v[0], v[1], v[2], v[3]);
+    o[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// obs [B,C,S,S] -> out [B*(S/4)^2, C*16], k = c*16 + ky*4 + kx  (matches W[64,C,4,4] flattened)
+__global__ void patchify4_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int S) {
+    const int E = S / 4;
+    const long long n = (long long)B * E * E * C * 4;   // one thread per (row, c, ky): 4 contiguous kx
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ky = i & 3;
+    const int c = (i >> 2) % C;
+    const long long row = (i >> 2) / C;
+    const int ex = row % E, ey = (row / E) % E;
+    const long long b = row / ((long long)E * E);
+    const float4 v = *reinterpret_cast<const float4*>(in + ((b * C + c) * S + (ey * 4 + ky)) * S + ex * 4);
+    *reinterpret_cast<float4*>(out + row * (C * 16) + c * 16 + ky * 4) = v;
+}
+
+// PixelShuffle(2) in NHWC: out[b, 2h+i, 2w+j, c] = in[b, h, w, 4c + 2i + j]; forward==0 runs the inverse map.
+__global__ void pixel_shuffle_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h, int w, int Cout, int forward,
+                                     const float* __restrict__ mask) {
+    const long long n = (long long)B * h * w * 4 * Cout;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // enumerate the shuffled tensor [B,2h,2w,Cout]
+    const int c = i % Cout;
+    long long r = i / Cout;
+    const int X = r % (2 * w); r /= (2 * w);
+    const int Y = r % (2 * h);
+    const long long b = r / (2 * h);
+    const long long src = ((b * h + (Y >> 1)) * w + (X >> 1)) * (4 * Cout) + 4 * c + 2 * (Y & 1) + (X & 1);
+    if (forward) out[i] = in[src];
+    else out[src] = (mask && !(mask[src] > 0.f)) ? 0.f : in[i];     // backward: optional ReLU mask on the unshuffled tensor
+}
+
+// ------------------------------------------------------------------ LayerNorm (eps 1e-5, biased variance)
+template <int NPL>   // F = 64 * NPL, one wave per row
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
+                                     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long long R) {
+    constexpr int F = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { v[i] = x[row * F + i * 64 + lane]; s += v[i]; }
+    const float mu = wave_sum(s) * (1.0f / F);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { const float d = v[i] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / F) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int c = i * 64 + lane;
+        y[row * F + c] = (v[i] - mu) * rs * g[c] + bta[c];
+    }
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)); block partials of dgamma/dbeta -> part[blk][2F]
+template <int NPL>
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx,
+                                     float* __restrict__ part, long long R, int accumulate) {
+    constexpr int F = 64 * NPL;
+    __shared__ float red[4][2 * F];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float dg[NPL], db[NPL], gg[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { dg[i] = 0.f; db[i] = 0.f; gg[i] = g[i * 64 + lane]; }
+    for (long long row = (long long)blockIdx.x * 4 + wv; row < R; row += (long long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[NPL], d[NPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int c = i * 64 + lane;
+            xh[i] = (x[row * F + c] - mu) * rs;
+            const float dyv = dy[row * F + c];
+            dg[i] += dyv * xh[i];
+            db[i] += dyv;
+            d[i] = dyv * gg[i];
+            s1 += d[i];
+            s2 += d[i] * xh[i];
+        }
+        s1 = wave_sum(s1) * (1.0f / F);
+        s2 = wave_sum(s2) * (1.0f / F);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int c = i * 64 + lane;
+            const float v = rs * (d[i] - s1 - xh[i] * s2);
+            dx[row * F + c] = accumulate ? dx[row * F + c] + v : v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { red[wv][i * 64 + lane] = dg[i]; red[wv][F + i * 64 + lane] = db[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * F; c += blockDim.x)
+        part[(size_t)blockIdx.x * 2 * F + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients etc.)
+// part[chunk][F] = sum over the chunk's rows of X[r][f]
+__global__ void colsum_kernel(const float* __restrict__ X, long long ld, float* __restrict__ part, long long R, int F, long long rows_per_chunk) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    const long long r1 = min(R, r0 + rows_per_chunk);
+    float s = 0.f;
+    if (col < F)
+        for (long long r = r0 + rl; r < r1; r += 4) s += X[r * ld + col];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < F) part[(size_t)blockIdx.y * F + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int F, int accumulate, float scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * F + c];
+    s *= scale;
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// out[0] (+)= scale * sum(part[0..n))   — single block, deterministic
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out, float scale, int accumulate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s * scale;
+}
+
+// ------------------------------------------------------------------ dVAE reconstruction loss
+// obs [B,C,H,W] vs recon [B,H,W,4]: part[blk] = sum (obs-recon)^2 ; drecon = 2*(recon-obs)*inv_b (pad channel 0)
+__global__ void mse_kernel(const float* __restrict__ obs, const float* __restrict__ recon, float* __restrict__ drecon,
+                           float* __restrict__ part, int B, int C, int H, int W, float inv_b) {
+    __shared__ float red[4];
+    const long long n = (long long)B * H * W, hw = (long long)H * W;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, r = i % hw;
+        const float4 rc = *reinterpret_cast<const float4*>(recon + i * 4);
+        const float rv[4] = {rc.x, rc.y, rc.z, rc.w};
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float e = rv[c] - obs[(b * C + c) * hw + r];
+            s += e * e;
+            d[c] = 2.f * e * inv_b;
+        }
+        if (drecon) *reinterpret_cast<float4*>(drecon + i * 4) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------ Gumbel softmax over the vocabulary
+// One workgroup per row of V logits.  logp = log_softmax(raw); z = softmax((logp + g1)/tau);
+// tok = argmax(logp + g2);  g = -log(e + tiny), e ~ Exp(1) injected (e1/e2) or drawn on device.
+#define GS_MAXPT 16
+__global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __restrict__ raw, const float* __restrict__ e1,
+                                                             const float* __restrict__ e2, float* __restrict__ z,
+                                                             int* __restrict__ tokens, int V, float inv_tau,
+                                                             unsigned long long seed) {
+    __shared__ float red[4];
+    __shared__ float redv[4];
+    __shared__ int redi[4];
+    const long long row = blockIdx.x;
+    const float* r = raw + row * V;
+    const int npt = V / 256;     // V % 256 == 0, V <= 4096
+    float x[GS_MAXPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) { x[i] = r[i * 256 + threadIdx.x]; mx = fmaxf(mx, x[i]); }
+    mx = block_max(mx, red);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) s += __expf(x[i] - mx);
+    s = block_sum(s, red);
+    const float lse = mx + __logf(s);
+    // soft sample
+    float u[GS_MAXPT];
+    float best = -INFINITY;
+    int besti = 0;
+    float m2 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) {
+            const int v = i * 256 + threadIdx.x;
+            const float lp = x[i] - lse;
+            float ea, eb;
+            if (e1) { ea = e1[row * V + v]; eb = e2[row * V + v]; }
+            else {
+                const uint64_t idx = (uint64_t)row * V + v;
+                const uint2 ba = rng_bits4(seed, SITE_GUMBEL_Z, idx);
+                ea = -__logf(u01_24(ba.x));
+                eb = -__logf(u01_24(ba.y));
+            }
+            const float g1 = -__logf(ea + TINYF), g2 = -__logf(eb + TINYF);
+            u[i] = (lp + g1) * inv_tau;
+            m2 = fmaxf(m2, u[i]);
+            const float h = (lp + g2) * inv_tau;
+            if (h > best) { best = h; besti = v; }
+        }
+    m2 = block_max(m2, red);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) { u[i] = __expf(u[i] - m2); s2 += u[i]; }
+    s2 = block_sum(s2, red);
+    const float inv = 1.0f / s2;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) z[row * V + i * 256 + threadIdx.x] = u[i] * inv;
+    // argmax (first index wins ties, like torch.argmax on CPU)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { redv[w] = best; redi[w] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (redv[k] > best || (redv[k] == best && redi[k] < besti)) { best = redv[k]; besti = redi[k]; }
+        tokens[row] = besti;
+    }
+}
+
+// in place: d[v] = z[v] * (d[v] - sum_v z*d) * scale     (softmax backward for one row of V)
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ z, float* __restrict__ d, int V, float scale) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += z[row * V + v] * d[row * V + v];
+    s = block_sum(s, red);
+    for (int v = threadIdx.x; v < V; v += 256) d[row * V + v] = z[row * V + v] * (d[row * V + v] - s) * scale;
+}
+
+// cross entropy with hard targets, one workgroup per row: part[row] = lse - pred[tok];
+// pred <- (softmax(pred) - onehot(tok)) * inv_b   (in place gradient)
+__global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ pred, const int* __restrict__ tokens, float* __restrict__ part,
+                                                 int V, float inv_b, int write_grad) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    float* r = pred + row * V;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, r[v]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += __expf(r[v] - mx);
+    s = block_sum(s, red);
+    const int tok = tokens[row];
+    if (threadIdx.x == 0) part[row] = (mx + __logf(s)) - r[tok];
+    if (write_grad) {
+        const float inv = 1.0f / s;
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float pr = __expf(r[v] - mx) * inv;
+            r[v] = (pr - (v == tok ? 1.f : 0.f)) * inv_b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ token embedding (+BOS, +pos, dropout)
+// out[b,t,:] = drop( (t==0 ? bos : dict[tok[b,t-1]]) + pe[t] ),  dropout index over the reference's [B,T+1,d] tensor
+__global__ void embed_fwd_kernel(const int* __restrict__ tokens, const float* __restrict__ dict, const float* __restrict__ bos,
+                                 const float* __restrict__ pe, float* __restrict__ out, int B, int T, int d, float p,
+                                 unsigned long long seed) {
+    const int d4 = d / 4;
+    const long long n = (long long)B * T * d4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c4 = i % d4;
+    const long long bt = i / d4;
+    const int t = bt % T;
+    const long long b = bt / T;
+    const float* src = t == 0 ? bos : dict + (size_t)tokens[b * T + t - 1] * d;
+    float4 v = *reinterpret_cast<const float4*>(src + c4 * 4);
+    const float4 pv = *reinterpret_cast<const float4*>(pe + (size_t)t * d + c4 * 4);
+    v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+    if (p > 0.f) {
+        const uint64_t idx4 = ((uint64_t)(b * (T + 1) + t) * d) / 4 + c4;
+        const uint2 bits = rng_bits4(seed, SITE_ZPOS, idx4);
+        const uint32_t thr = drop_thresh(p);
+        const float sc = 1.0f / (1.0f - p);
+        v.x = rng_keep(bits, 0, thr) ? v.x * sc : 0.f;
+        v.y = rng_keep(bits, 1, thr) ? v.y * sc : 0.f;
+        v.z = rng_keep(bits, 2, thr) ? v.z * sc : 0.f;
+        v.w = rng_keep(bits, 3, thr) ? v.w * sc : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+}
+
+// g <- dropout-backward(g) in place; ddict[tok] += g (atomics).  dpe/dbos come from a column sum over b.
+__global__ void embed_bwd_kernel(float* __restrict__ g, const int* __restrict__ tokens, float* __restrict__ ddict, int B, int T,
+                                 int d, float p, unsigned long long seed) {
+    const int d4 = d / 4;
+    const long long n = (long long)B * T * d4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c4 = i % d4;
+    const long long bt = i / d4;
+    const int t = bt % T;
+    const long long b = bt / T;
+    float4 v = *reinterpret_cast<float4*>(g + i * 4);
+    if (p > 0.f) {
+        const uint64_t idx4 = ((uint64_t)(b * (T + 1) + t) * d) / 4 + c4;
+        const uint2 bits = rng_bits4(seed, SITE_ZPOS, idx4);
+        const uint32_t thr = drop_thresh(p);
+        const float sc = 1.0f / (1.0f - p);
+        v.x = rng_keep(bits, 0, thr) ? v.x * sc : 0.f;
+        v.y = rng_keep(bits, 1, thr) ? v.y * sc : 0.f;
+        v.z = rng_keep(bits, 2, thr) ? v.z * sc : 0.f;
+        v.w = rng_keep(bits, 3, thr) ? v.w * sc : 0.f;
+        *reinterpret_cast<float4*>(g + i * 4) = v;
+    }
+    if (t > 0) {
+        float* dst = ddict + (size_t)tokens[b * T + t - 1] * d + c4 * 4;
+        atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+    }
+}
+
+// y = x * keep/(1-p) for the dropout site (n % 4 == 0); index = element offset
+__global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p,
+                                     unsigned long long seed, unsigned site) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const uint2 bits = rng_bits4(seed, site, (uint64_t)i);
+    const uint32_t thr = drop_thresh(p);
+    const float sc = 1.0f / (1.0f - p);
+    v.x = rng_keep(bits, 0, thr) ? v.x * sc : 0.f;
+    v.y = rng_keep(bits, 1, thr) ? v.y * sc : 0.f;
+    v.z = rng_keep(bits, 2, thr) ? v.z * sc : 0.f;
+    v.w = rng_keep(bits, 3, thr) ? v.w * sc : 0.f;
+    *reinterpret_cast<float4*>(y + i * 4) = v;
+}
+// keep-mask dump (float 0/1) for the parity tests: exactly the decisions the kernels take
+__global__ void dropout_mask_kernel(float* __restrict__ y, long long n, float p, unsigned long long seed, unsigned site) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 bits = rng_bits4(seed, site, (uint64_t)(i >> 2));
+    y[i] = rng_keep(bits, (int)(i & 3), drop_thresh(p)) ? 1.f : 0.f;
+}
+
+// ------------------------------------------------------------------ causal softmax on materialised scores
+// S [BH,T,T] (scores, already scaled) -> P (softmax with -inf above the diagonal) written in place,
+// Pd = dropout(P) written to Pd (may alias S when p == 0).  One workgroup per row.
+__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(float* __restrict__ S, float* __restrict__ Pd, int T, float p,
+                                                                 unsigned long long seed, unsigned site) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;          // bh*T + q
+    const int q = row % T;
+    float* r = S + row * T;
+    float mx = -INFINITY;
+    for (int k = threadIdx.x; k <= q; k += 256) mx = fmaxf(mx, r[k]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int k = threadIdx.x; k <= q; k += 256) s += __expf(r[k] - mx);
+    s = block_sum(s, red);
+    const float inv = 1.0f / s;
+    const uint32_t thr = drop_thresh(p);
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+    for (int k = threadIdx.x; k < T; k += 256) {
+        const float pr = k <= q ? __expf(r[k] - mx) * inv : 0.f;
+        float pd = pr;
+        if (p > 0.f) {
+            const uint64_t idx = (uint64_t)row * T + k;
+            pd = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? pr * sc : 0.f;
+        }
+        r[k] = pr;
+        Pd[row * T + k] = pd;
+    }
+}
+// dPd (in place -> dS):  dP = keep/(1-p) * dPd ; dS = P * (dP - sum_k P*dP)
+__global__ __launch_bounds__(256) void softmax_causal_bwd_kernel(const float* __restrict__ P, float* __restrict__ dPd, int T, float p,
+                                                                 unsigned long long seed, unsigned site) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const int q = row % T;
+    const uint32_t thr = drop_thresh(p);
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+    float s = 0.f;
+    for (int k = threadIdx.x; k <= q; k += 256) {
+        float dp = dPd[row * T + k];
+        if (p > 0.f) {
+            const uint64_t idx = (uint64_t)row * T + k;
+            dp = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? dp * sc : 0.f;
+        }
+        s += P[row * T + k] * dp;
+    }
+    s = block_sum(s, red);
+    for (int k = threadIdx.x; k < T; k += 256) {
+        float v = 0.f;
+        if (k <= q) {
+            float dp = dPd[row * T + k];
+            if (p > 0.f) {
+                const uint64_t idx = (uint64_t)row * T + k;
+                dp = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? dp * sc : 0.f;
+            }
+            v = P[row * T + k] * (dp - s);
+        }
+        dPd[row * T + k] = v;
+    }
+}
+
+// ------------------------------------------------------------------ cross attention to K (<= 8) slots
+// Q [B,T,d] (projected, unscaled), Km/Vm [B,K,d], heads h, dh = d/h (<= 64).  One thread per (b,head,q).
+// P [B,h,T,K] = softmax (pre-dropout) is saved for the backward.
+#define CA_MAXK 8
+#define CA_MAXDH 64
+__global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Km,
+                                                             const float* __restrict__ Vm, float* __restrict__ O,
+                                                             float* __restrict__ P, int T, int K, int d, int h, float p,
+                                                             unsigned long long seed, unsigned site) {
+    extern __shared__ float sm[];   // Ks [K][dh], Vs [K][dh]
+    const int dh = d / h;
+    const int nqb = (T + 255) / 256;
+    int bid = blockIdx.x;
+    const int qb = bid % nqb; bid /= nqb;
+    const int hd = bid % h;
+    const long long b = bid / h;
+    float* Ks = sm;
+    float* Vs = sm + K * dh;
+    for (int i = threadIdx.x; i < K * dh; i += 256) {
+        const int k = i / dh, c = i % dh;
+        Ks[i] = Km[(b * K + k) * d + hd * dh + c];
+        Vs[i] = Vm[(b * K + k) * d + hd * dh + c];
+    }
+    __syncthreads();
+    const int q = qb * 256 + threadIdx.x;
+    if (q >= T) return;
+    const float scale = rsqrtf((float)dh);
+    float qv[CA_MAXDH];
+    const float* qp = Q + (b * T + q) * d + hd * dh;
+#pragma unroll
+    for (int c = 0; c < CA_MAXDH; c += 4)
+        if (c < dh) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + c);
+            qv[c] = v.x * scale; qv[c + 1] = v.y * scale; qv[c + 2] = v.z * scale; qv[c + 3] = v.w * scale;
+        }
+    float s[CA_MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CA_MAXK; ++k)
+        if (k < K) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < CA_MAXDH; ++c)
+                if (c < dh) a += qv[c] * Ks[k * dh + c];
+            s[k] = a;
+            mx = fmaxf(mx, a);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < CA_MAXK; ++k)
+        if (k < K) { s[k] = __expf(s[k] - mx); sum += s[k]; }
+    const float inv = 1.0f / sum;
+    const uint32_t thr = drop_thresh(p);
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+    const long long prow = ((b * h + hd) * T + q) * K;
+    float o[CA_MAXDH];
+#pragma unroll
+    for (int c = 0; c < CA_MAXDH; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < CA_MAXK; ++k)
+        if (k < K) {
+            const float pr = s[k] * inv;
+            P[prow + k] = pr;
+            float pd = pr;
+            if (p > 0.f) {
+                const uint64_t idx = (uint64_t)prow + k;
+                pd = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? pr * sc : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < CA_MAXDH; ++c)
+                if (c < dh) o[c] += pd * Vs[k * dh + c];
+        }
+    float* op = O + (b * T + q) * d + hd * dh;
+#pragma unroll
+    for (int c = 0; c < CA_MAXDH; c += 4)
+        if (c < dh) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+}
+
+// backward: dQ [B,T,d] written; dKm/dVm [B,K,d] accumulated with atomics (must be zeroed by the caller)
+__global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
+                                                             const float* __restrict__ Km, const float* __restrict__ Vm,
+                                                             const float* __restrict__ P, float* __restrict__ dQ,
+                                                             float* __restrict__ dKm, float* __restrict__ dVm, int T, int K, int d,
+                                                             int h, float p, unsigned long long seed, unsigned site) {
+    extern __shared__ float sm[];   // Ks, Vs, dKs, dVs  [K][dh] each
+    const int dh = d / h;
+    const int nqb = (T + 255) / 256;
+    int bid = blockIdx.x;
+    const int qb = bid % nqb; bid /= nqb;
+    const int hd = bid % h;
+    const long long b = bid / h;
+    float* Ks = sm;
+    float* Vs = sm + K * dh;
+    float* dKs = sm + 2 * K * dh;
+    float* dVs = sm + 3 * K * dh;
+    for (int i = threadIdx.x; i < K * dh; i += 256) {
+        const int k = i / dh, c = i % dh;
+        Ks[i] = Km[(b * K + k) * d + hd * dh + c];
+        Vs[i] = Vm[(b * K + k) * d + hd * dh + c];
+        dKs[i] = 0.f;
+        dVs[i] = 0.f;
+    }
+    __syncthreads();
+    const int q = qb * 256 + threadIdx.x;
+    if (q < T) {
+        const float scale = rsqrtf((float)dh);
+        float qv[CA_MAXDH], go[CA_MAXDH], dq[CA_MAXDH];
+        const float* qp = Q + (b * T + q) * d + hd * dh;
+        const float* gp = dO + (b * T + q) * d + hd * dh;
+#pragma unroll
+        for (int c = 0; c < CA_MAXDH; ++c)
+            if (c < dh) { qv[c] = qp[c] * scale; go[c] = gp[c]; dq[c] = 0.f; }
+        const uint32_t thr = drop_thresh(p);
+        const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
+        const long long prow = ((b * h + hd) * T + q) * K;
+        float pr[CA_MAXK], dp[CA_MAXK];
+        float delta = 0.f;
+#pragma unroll
+        for (int k = 0; k < CA_MAXK; ++k)
+            if (k < K) {
+                pr[k] = P[prow + k];
+                float keep = 1.f;
+                if (p > 0.f) {
+                    const uint64_t idx = (uint64_t)prow + k;
+                    keep = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? sc : 0.f;
+                }
+                float a = 0.f;
+#pragma unroll
+                for (int c = 0; c < CA_MAXDH; ++c)
+                    if (c < dh) a += go[c] * Vs[k * dh + c];
+                dp[k] = a * keep;
+                delta += pr[k] * dp[k];
+                const float pd = pr[k] * keep;
+#pragma unroll
+                for (int c = 0; c < CA_MAXDH; ++c)
+                    if (c < dh) atomicAdd(&dVs[k * dh + c], pd * go[c]);
+            }
+#pragma unroll
+        for (int k = 0; k < CA_MAXK; ++k)
+            if (k < K) {
+                const float ds = pr[k] * (dp[k] - delta);
+#pragma unroll
+                for (int c = 0; c < CA_MAXDH; ++c)
+                    if (c < dh) {
+                        dq[c] += ds * Ks[k * dh + c];
+                        atomicAdd(&dKs[k * dh + c], ds * qv[c]);
+                    }
+            }
+        float* dqp = dQ + (b * T + q) * d + hd * dh;
+#pragma unroll
+        for (int c = 0; c < CA_MAXDH; ++c)
+            if (c < dh) dqp[c] = dq[c] * scale;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * dh; i += 256) {
+        const int k = i / dh, c = i % dh;
+        atomicAdd(&dKm[(b * K + k) * d + hd * dh + c], dKs[i]);
+        atomicAdd(&dVm[(b * K + k) * d + hd * dh + c], dVs[i]);
+    }
+}
+
+// ------------------------------------------------------------------ misc
+__global__ void fill_kernel(float* __restrict__ x, long long n, float v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = v;
+}
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+// posmap[y,x,c] = sum_j grid[j,y,x] * Wpos[c,j] + bpos[c]   (grid = [north, south, west, east] ramps)
+__global__ void posmap_kernel(const float* __restrict__ Wpos, const float* __restrict__ bpos, float* __restrict__ out, int S, int C) {
+    const long long n = (long long)S * S * C;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = i % C;
+    const int x = (i / C) % S, y = i / ((long long)C * S);
+    const float east = S > 1 ? (float)x / (float)(S - 1) : 0.f, south = S > 1 ? (float)y / (float)(S - 1) : 0.f;
+    const float west = 1.f - east, north = 1.f - south;
+    out[i] = north * Wpos[c * 4 + 0] + south * Wpos[c * 4 + 1] + west * Wpos[c * 4 + 2] + east * Wpos[c * 4 + 3] + bpos[c];
+}
+// gridT[(y*S+x)*4 + j]: the position grid as an [S*S,4] matrix (for the pos-embedding weight gradient GEMM)
+__global__ void posgrid_kernel(float* __restrict__ out, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * S) return;
+    const int x = i % S, y = i / S;
+    const float east = S > 1 ? (float)x / (float)(S - 1) : 0.f, south = S > 1 ? (float)y / (float)(S - 1) : 0.f;
+    *reinterpret_cast<float4*>(out + (size_t)i * 4) = make_float4(1.f - south, south, 1.f - east, east);
+}
+// copy a [R, C] matrix into a [R, ldo] one (ldo >= C), zero padding; and back (pad==0)
+__global__ void pad_cols_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, long long R, int C, int Cout) {
+    const long long n = R * Cout;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = i % Cout;
+    const long long r = i / Cout;
+    out[r * ldo + c] = c < C ? in[r * ldi + c] : 0.f;
+}
+
+// slots0[r][c] = mu[c] + exp(logsig[c]) * eps[r][c]; eps injected (noise) or N(0,1) drawn on device (Box-Muller)
+__device__ inline float slot_eps(const float* noise, long long i, unsigned long long seed) {
+    if (noise) return noise[i];
+    const uint2 b = rng_bits4(seed, SITE_SLOT_NOISE, (uint64_t)i);
+    return sqrtf(-2.0f * __logf(u01_24(b.x))) * __cosf(6.2831853f * u01_24(b.y));
+}
+__global__ void slot_init_kernel(const float* __restrict__ mu, const float* __restrict__ logsig, const float* __restrict__ noise,
+                                 float* __restrict__ slots0, long long n, int D, unsigned long long seed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = i % D;
+    slots0[i] = mu[c] + __expf(logsig[c]) * slot_eps(noise, i, seed);
+}
+// one thread per column: dmu[c] = sum_r d[r][c]; dlogsig[c] = sum_r d[r][c] * exp(logsig[c]) * eps[r][c]
+__global__ void slot_init_bwd_kernel(const float* __restrict__ d, const float* __restrict__ logsig, const float* __restrict__ noise,
+                                     float* __restrict__ dmu, float* __restrict__ dlogsig, int R, int D, unsigned long long seed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float g = d[(size_t)r * D + c];
+        a += g;
+        b += g * slot_eps(noise, (long long)r * D + c, seed);
+    }
+    dmu[c] = a;
+    dlogsig[c] = b * __expf(logsig[c]);
+}
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ================================================================== launchers
+#define GRID1D(n) dim3(cdiv((n), 256)), dim3(256)
+
+int nchw_to_nhwc8_launch(const float* in, float* out, int B, int C, int H, int W, hipStream_t st) {
+    OCRL_REQUIRE(C <= 8, "nchw_to_nhwc8: C must be <= 8");
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, GRID1D(n), 0, st, in, out, B, C, H, W);
+    OCRL_CHECK_LAUNCH("nchw_to_nhwc8");
+    return 0;
+}
+int patchify4_launch(const float* in, float* out, int B, int C, int S, hipStream_t st) {
+    OCRL_REQUIRE(S % 4 == 0, "patchify4: S %% 4 != 0");
+    const long long n = (long long)B * (S / 4) * (S / 4) * C * 4;
+    hipLaunchKernelGGL(patchify4_kernel, GRID1D(n), 0, st, in, out, B, C, S);
+    OCRL_CHECK_LAUNCH("patchify4");
+    return 0;
+}
+int pixel_shuffle_launch(const float* in, float* out, int B, int h, int w, int Cout, int forward, const float* mask, hipStream_t st) {
+    const long long n = (long long)B * h * w * 4 * Cout;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, GRID1D(n), 0, st, in, out, B, h, w, Cout, forward, mask);
+    OCRL_CHECK_LAUNCH("pixel_shuffle");
+    return 0;
+}
+int layernorm_fwd_launch(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, long long R, int F, hipStream_t st) {
+    OCRL_REQUIRE(F % 64 == 0 && F >= 64 && F <= 256, "layernorm: F must be 64..256, multiple of 64 (got %d)", F);
+    dim3 grid(cdiv(R, 4)), blk(256);
+    switch (F / 64) {
+        case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
+        case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
+        case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
+        default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
+    }
+    OCRL_CHECK_LAUNCH("layernorm_fwd");
+    return 0;
+}
+int colsum_launch(const float* X, long long ld, float* out, long long R, int F, int accumulate, float scale, float* ws, size_t ws_floats, hipStream_t st) {
+    const int cb = cdiv(F, 64);
+    long long nchunk = 1024 / cb;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > (R + 63) / 64) nchunk = (R + 63) / 64;
+    if (nchunk < 1) nchunk = 1;
+    OCRL_REQUIRE((size_t)nchunk * F <= ws_floats, "colsum: workspace too small (%lld x %d)", nchunk, F);
+    const long long rpc = (R + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cb, (int)nchunk), dim3(256), 0, st, X, ld, ws, R, F, rpc);
+    OCRL_CHECK_LAUNCH("colsum");
+    hipLaunchKernelGGL(colsum_final_kernel, GRID1D(F), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
+    OCRL_CHECK_LAUNCH("colsum_final");
+    return 0;
+}
+int layernorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* g, float* dx,
+                         float* dgb, long long R, int F, int accumulate_dx, int accumulate_dgb, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(F % 64 == 0 && F >= 64 && F <= 256, "layernorm bwd: F must be 64..256, multiple of 64 (got %d)", F);
+    int nblk = (int)((R + 3) / 4);
+    if (nblk > 512) nblk = 512;
+    const size_t need = (size_t)nblk * 2 * F;
+    OCRL_REQUIRE(need + (size_t)8 * 2 * F <= ws_floats, "layernorm bwd: workspace too small");
+    dim3 grid(nblk), blk(256);
+    switch (F / 64) {
+        case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
+        case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
+        case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
+        default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
+    }
+    OCRL_CHECK_LAUNCH("layernorm_bwd");
+    return colsum_launch(ws, 2 * F, dgb, nblk, 2 * F, accumulate_dgb, 1.f, ws + need, ws_floats - need, st);
+}
+int reduce_partials_launch(const float* part, int n, float* out, float scale, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, part, n, out, scale, accumulate);
+    OCRL_CHECK_LAUNCH("reduce_partials");
+    return 0;
+}
+int mse_launch(const float* obs, const float* recon, float* drecon, float* out, int B, int C, int H, int W, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(C <= 4, "mse: C must be <= 4");
+    const int nblk = 1024;
+    OCRL_REQUIRE(ws_floats >= (size_t)nblk, "mse: workspace too small");
+    hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, st, obs, recon, drecon, ws, B, C, H, W, 1.0f / B);
+    OCRL_CHECK_LAUNCH("mse");
+    return reduce_partials_launch(ws, nblk, out, 1.0f / B, 0, st);
+}
+int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, float* z, int* tokens, long long R, int V, float tau,
+                          unsigned long long seed, hipStream_t st) {
+    OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "gumbel_softmax: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
+    OCRL_REQUIRE((e1 == nullptr) == (e2 == nullptr), "gumbel_softmax: give both noise tensors or none");
+    hipLaunchKernelGGL(gumbel_softmax_kernel, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed);
+    OCRL_CHECK_LAUNCH("gumbel_softmax");
+    return 0;
+}
+int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, st, z, d, V, scale);
+    OCRL_CHECK_LAUNCH("softmax_bwd_rows");
+    return 0;
+}
+int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(ws_floats >= (size_t)R, "ce: workspace too small");
+    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)R), dim3(256), 0, st, pred, tokens, ws, V, 1.0f / B, write_grad);
+    OCRL_CHECK_LAUNCH("ce");
+    return reduce_partials_launch(ws, (int)R, out, 1.0f / B, 0, st);
+}
+int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,
+                     unsigned long long seed, hipStream_t st) {
+    OCRL_REQUIRE(d % 4 == 0, "embed: d %% 4 != 0");
+    const long long n = (long long)B * T * (d / 4);
+    hipLaunchKernelGGL(embed_fwd_kernel, GRID1D(n), 0, st, tokens, dict, bos, pe, out, B, T, d, p, seed);
+    OCRL_CHECK_LAUNCH("embed_fwd");
+    return 0;
+}
+int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int d, float p, unsigned long long seed, hipStream_t st) {
+    const long long n = (long long)B * T * (d / 4);
+    hipLaunchKernelGGL(embed_bwd_kernel, GRID1D(n), 0, st, g, tokens, ddict, B, T, d, p, seed);
+    OCRL_CHECK_LAUNCH("embed_bwd");
+    return 0;
+}
+int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+    OCRL_REQUIRE(n % 4 == 0, "dropout_apply: n %% 4 != 0");
+    hipLaunchKernelGGL(dropout_apply_kernel, GRID1D(n / 4), 0, st, x, y, n / 4, p, seed, site);
+    OCRL_CHECK_LAUNCH("dropout_apply");
+    return 0;
+}
+int dropout_mask_launch(float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_mask_kernel, GRID1D(n), 0, st, y, n, p, seed, site);
+    OCRL_CHECK_LAUNCH("dropout_mask");
+    return 0;
+}
+int softmax_causal_fwd_launch(float* S, float* Pd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_causal_fwd_kernel, dim3((unsigned)(BH * T)), dim3(256), 0, st, S, Pd, T, p, seed, site);
+    OCRL_CHECK_LAUNCH("softmax_causal_fwd");
+    return 0;
+}
+int softmax_causal_bwd_launch(const float* P, float* dPd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_causal_bwd_kernel, dim3((unsigned)(BH * T)), dim3(256), 0, st, P, dPd, T, p, seed, site);
+    OCRL_CHECK_LAUNCH("softmax_causal_bwd");
+    return 0;
+}
+int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, float* O, float* P, int B, int T, int K, int d, int h, float p,
+                          unsigned long long seed, unsigned site, hipStream_t st) {
+    OCRL_REQUIRE(K <= CA_MAXK && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
+    const int grid = B * h * cdiv(T, 256);
+    hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3(grid), dim3(256), 2 * K * (d / h) * 4, st, Q, Km, Vm, O, P, T, K, d, h, p, seed, site);
+    OCRL_CHECK_LAUNCH("cross_attn_fwd");
+    return 0;
+}
+int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
+                          int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+    OCRL_REQUIRE(K <= CA_MAXK && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
+    const int grid = B * h * cdiv(T, 256);
+    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3(grid), dim3(256), 4 * K * (d / h) * 4, st, dO, Q, Km, Vm, P, dQ, dKm, dVm, T, K, d, h, p, seed, site);
+    OCRL_CHECK_LAUNCH("cross_attn_bwd");
+    return 0;
+}
+int fill_launch(float* x, long long n, float v, hipStream_t st) {
+    hipLaunchKernelGGL(fill_kernel, GRID1D(n), 0, st, x, n, v);
+    OCRL_CHECK_LAUNCH("fill");
+    return 0;
+}
+int axpy_launch(const float* x, float* y, long long n, float a, hipStream_t st) {
+    hipLaunchKernelGGL(axpy_kernel, GRID1D(n), 0, st, x, y, n, a);
+    OCRL_CHECK_LAUNCH("axpy");
+    return 0;
+}
+int posmap_launch(const float* Wpos, const float* bpos, float* out, int S, int C, hipStream_t st) {
+    hipLaunchKernelGGL(posmap_kernel, GRID1D((long long)S * S * C), 0, st, Wpos, bpos, out, S, C);
+    OCRL_CHECK_LAUNCH("posmap");
+    return 0;
+}
+int posgrid_launch(float* out, int S, hipStream_t st) {
+    hipLaunchKernelGGL(posgrid_kernel, GRID1D(S * S), 0, st, out, S);
+    OCRL_CHECK_LAUNCH("posgrid");
+    return 0;
+}
+int pad_cols_launch(const float* in, int ldi, float* out, int ldo, long long R, int C, int Cout, hipStream_t st) {
+    hipLaunchKernelGGL(pad_cols_kernel, GRID1D(R * Cout), 0, st, in, ldi, out, ldo, R, C, Cout);
+    OCRL_CHECK_LAUNCH("pad_cols");
+    return 0;
+}
+int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st) {
+    const long long n = (long long)BK * D;
+    hipLaunchKernelGGL(slot_init_kernel, GRID1D(n), 0, st, mu, logsig, noise, slots0, n, D, seed);
+    OCRL_CHECK_LAUNCH("slot_init");
+    return 0;
+}
+int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float* noise, float* dmu, float* dlogsig, int BK, int D, unsigned long long seed, hipStream_t st) {
+    hipLaunchKernelGGL(slot_init_bwd_kernel, GRID1D(D), 0, st, dslots0, logsig, noise, dmu, dlogsig, BK, D, seed);
+    OCRL_CHECK_LAUNCH("slot_init_bwd");
+    return 0;
+}
+int copy_launch(const float* src, float* dst, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(copy_kernel, GRID1D(n), 0, st, src, dst, n);
+    OCRL_CHECK_LAUNCH("copy");
+    return 0;
+}

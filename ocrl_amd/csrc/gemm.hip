@@ -1,0 +1,280 @@
+// fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, gfx950) with fused epilogues.
+//
+//   C[m,n] = epi( alpha * sum_k A(m,k) * B(k,n) )
+//
+// Operand storage is selected per operand:
+//   AKC : A stored [M,K] (k contiguous, lda)        else A stored [K,M] (m contiguous, lda)
+//   BKC : B stored [N,K] (k contiguous, ldb)        else B stored [K,N] (n contiguous, ldb)
+// which covers  y = x W^T (AKC,BKC),  dx = dy W (AKC,!BKC),  dW = dy^T x (!AKC,!BKC).
+//
+// 256 threads = 4 waves in a 2x2 grid; each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles.
+// K is consumed in 32-wide tiles, double-buffered in LDS with register prefetch (one barrier
+// per k-tile).  Within a tile, the k index fed to MFMA step j by lane-half h is  8*c + 4*h + j
+// for both operands, so a k-contiguous operand is one ds_read_b128 per 32 rows per 8 k.
+#include "common.h"
+#include "kernels.h"
+
+#define BK 32
+
+template <int BM, bool KC>
+struct TileA {
+    // KC: [BM][BK+4]   !KC: [BK][BM+4]
+    static constexpr int LD = KC ? (BK + 4) : (BM + 4);
+    static constexpr int ELEMS = KC ? BM * (BK + 4) : BK * (BM + 4);
+    static constexpr int NV = BM / 32;  // float4 per thread per k-tile
+};
+
+// global -> registers for one operand tile.  rows = extent along m (or n), base points at
+// element (row 0, k 0) of this block's tile.  rows_valid / k_valid bound the loads; anything
+// outside is zero.
+template <int BMN, bool KC>
+__device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_valid, int k_valid,
+                                 float4 (&r)[BMN / 32]) {
+    const int t = threadIdx.x;
+    if (KC) {
+        const int c4 = t & 7, r0 = t >> 3;
+#pragma unroll
+        for (int i = 0; i < BMN / 32; ++i) {
+            const int row = r0 + 32 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows_valid && c4 * 4 < k_valid) v = *reinterpret_cast<const float4*>(g + (size_t)row * ld + c4 * 4);
+            r[i] = v;
+        }
+    } else {
+        constexpr int F4 = BMN / 4;          // float4 per k-row
+        constexpr int RPP = 256 / F4;        // k-rows per pass
+        const int c4 = t % F4, r0 = t / F4;
+#pragma unroll
+        for (int i = 0; i < BMN / 32; ++i) {
+            const int kr = r0 + RPP * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kr < k_valid && c4 * 4 < rows_valid) v = *reinterpret_cast<const float4*>(g + (size_t)kr * ld + c4 * 4);
+            r[i] = v;
+        }
+    }
+}
+
+template <int BMN, bool KC>
+__device__ inline void store_tile(float* __restrict__ s, const float4 (&r)[BMN / 32]) {
+    const int t = threadIdx.x;
+    constexpr int LD = TileA<BMN, KC>::LD;
+    if (KC) {
+        const int c4 = t & 7, r0 = t >> 3;
+#pragma unroll
+        for (int i = 0; i < BMN / 32; ++i) *reinterpret_cast<float4*>(s + (r0 + 32 * i) * LD + c4 * 4) = r[i];
+    } else {
+        constexpr int F4 = BMN / 4;
+        constexpr int RPP = 256 / F4;
+        const int c4 = t % F4, r0 = t / F4;
+#pragma unroll
+        for (int i = 0; i < BMN / 32; ++i) *reinterpret_cast<float4*>(s + (r0 + RPP * i) * LD + c4 * 4) = r[i];
+    }
+}
+
+// fragment for one 32-row MFMA tile, 8-k chunk c: f[j] is the operand of MFMA step j.
+template <int BMN, bool KC>
+__device__ inline void load_frag(const float* __restrict__ s, int row0, int c, float (&f)[4]) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    constexpr int LD = TileA<BMN, KC>::LD;
+    if (KC) {
+        const float4 v = *reinterpret_cast<const float4*>(s + (row0 + i) * LD + c * 8 + 4 * h);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = s[(c * 8 + 4 * h + j) * LD + row0 + i];
+    }
+}
+
+template <int BM, int BN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int AE = TileA<BM, AKC>::ELEMS, BE = TileA<BN, BKC>::ELEMS;
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * AE;
+
+    // block -> (tile, z) with an XCD-aware bijective remap of the tile index
+    const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
+    const int nwg = nbm * nbn;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int bn = bid % nbn, bm = bid / nbn;
+    const int z = blockIdx.y;
+    const int batch = z / p.splitk, split = z % p.splitk;
+    const int bo = batch / p.batch_inner, bi = batch % p.batch_inner;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int nkt = (p.K + BK - 1) / BK;
+    const int kt_per = (nkt + p.splitk - 1) / p.splitk;
+    const int kt0 = split * kt_per;
+    const int kt1 = min(nkt, kt0 + kt_per);
+
+    const float* A = p.A + (size_t)bo * p.sA + (size_t)bi * p.sAi;
+    const float* B = p.B + (size_t)bo * p.sB + (size_t)bi * p.sBi;
+    // tile base pointers at k = 0
+    const float* Ag = AKC ? A + (size_t)m0 * p.lda : A + m0;
+    const float* Bg = BKC ? B + (size_t)n0 * p.ldb : B + n0;
+    const int mval = p.M - m0, nval = p.N - n0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+    float4 ra[BM / 32], rb[BN / 32];
+    if (kt0 < kt1) {
+        const int k0 = kt0 * BK;
+        load_tile<BM, AKC>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra);
+        load_tile<BN, BKC>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb);
+        store_tile<BM, AKC>(As0, ra);
+        store_tile<BN, BKC>(Bs0, rb);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {
+            const int k0 = (kt + 1) * BK;
+            load_tile<BM, AKC>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra);
+            load_tile<BN, BKC>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb);
+        }
+        const float* as = As0 + cur * AE;
+        const float* bs = Bs0 + cur * BE;
+#pragma unroll
+        for (int c = 0; c < BK / 8; ++c) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_frag<BM, AKC>(as, wm0 + i * 32, c, fa[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_frag<BN, BKC>(bs, wn0 + j * 32, c, fb[j]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) {
+            store_tile<BM, AKC>(As0 + (cur ^ 1) * AE, ra);
+            store_tile<BN, BKC>(Bs0 + (cur ^ 1) * BE, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const bool partial = p.splitk > 1;
+    float* C = p.C + (size_t)bo * p.sC + (size_t)bi * p.sCi + (partial ? (size_t)split * p.sCsplit : 0);
+    const float* R = p.resid ? p.resid + (size_t)batch * p.sR : nullptr;
+    const float* Mk = p.mask ? p.mask + (size_t)batch * p.sMask : nullptr;
+    const uint32_t thr = drop_thresh(p.drop_p);
+    const float dscale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn0 + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha;
+                if (!partial) {
+                    v += bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.drop_p > 0.f) {
+                        const uint64_t idx = ((uint64_t)batch * p.M + row) * (uint64_t)p.N + col;
+                        const uint2 bits = rng_bits4(p.drop_seed, p.drop_site, idx >> 2);
+                        v = rng_keep(bits, (int)(idx & 3), thr) ? v * dscale : 0.f;
+                    }
+                    if (Mk) v = Mk[(size_t)row * p.ldmask + col] > 0.f ? v : 0.f;
+                    if (R) v += R[(size_t)row * p.ldr + col];
+                }
+                C[(size_t)row * p.ldc + col] = v;
+            }
+        }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i]
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n,
+                                     int splits, long long stride, int accumulate) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
+        for (int k = 0; k < splits; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = s;
+    } else {
+        for (long long e = i; e < n; ++e) {
+            float s = accumulate ? out[e] : 0.f;
+            for (int k = 0; k < splits; ++k) s += part[(size_t)k * stride + e];
+            out[e] = s;
+        }
+    }
+}
+
+template <int BM, int BN, bool AKC, bool BKC>
+static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = (2 * TileA<BM, AKC>::ELEMS + 2 * TileA<BN, BKC>::ELEMS) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, AKC, BKC>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.batch * a.splitk);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC>), grid, dim3(256), smem, st, a);
+    OCRL_CHECK_LAUNCH("gemm_kernel");
+    return 0;
+}
+
+template <bool AKC, bool BKC>
+static int launch_tr(const GemmArgs& a, hipStream_t st) {
+    if (a.N > 64) {
+        if (a.M > 64) return launch_cfg<128, 128, AKC, BKC>(a, st);
+        return launch_cfg<64, 128, AKC, BKC>(a, st);
+    }
+    if (a.M > 64) return launch_cfg<128, 64, AKC, BKC>(a, st);
+    return launch_cfg<64, 64, AKC, BKC>(a, st);
+}
+
+int gemm_launch(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
+    OCRL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d %d %d", a.M, a.N, a.K);
+    OCRL_REQUIRE(a.batch >= 1 && a.splitk >= 1, "gemm: bad batch/splitk");
+    if (a.akc) OCRL_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0, "gemm: A k-contiguous needs K,lda %% 4 == 0 (K=%d lda=%d)", a.K, a.lda);
+    else OCRL_REQUIRE(a.M % 4 == 0 && a.lda % 4 == 0, "gemm: A m-contiguous needs M,lda %% 4 == 0 (M=%d lda=%d)", a.M, a.lda);
+    if (a.bkc) OCRL_REQUIRE(a.K % 4 == 0 && a.ldb % 4 == 0, "gemm: B k-contiguous needs K,ldb %% 4 == 0 (K=%d ldb=%d)", a.K, a.ldb);
+    else OCRL_REQUIRE(a.N % 4 == 0 && a.ldb % 4 == 0, "gemm: B n-contiguous needs N,ldb %% 4 == 0 (N=%d ldb=%d)", a.N, a.ldb);
+    OCRL_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0, "gemm: operands must be 16-byte aligned");
+    OCRL_REQUIRE((a.sA % 4) == 0 && (a.sB % 4) == 0 && (a.sAi % 4) == 0 && (a.sBi % 4) == 0, "gemm: batch strides must be multiples of 4");
+    OCRL_REQUIRE(a.batch_inner >= 1 && a.batch % a.batch_inner == 0, "gemm: batch must be a multiple of batch_inner");
+    OCRL_REQUIRE(a.splitk == 1 || a.batch == 1, "gemm: split-k with batches is not supported");
+    if (a.splitk > 1) OCRL_REQUIRE(a.sCsplit >= (long long)(a.M - 1) * a.ldc + a.N, "gemm: split-k slab stride too small");
+    if (a.akc && a.bkc) return launch_tr<true, true>(a, st);
+    if (a.akc && !a.bkc) return launch_tr<true, false>(a, st);
+    if (!a.akc && !a.bkc) return launch_tr<false, false>(a, st);
+    return launch_tr<false, true>(a, st);
+}
+
+int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
+                         int accumulate, hipStream_t st) {
+    const long long thr = (n + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(thr, 256)), dim3(256), 0, st, part, out, n, splits, stride, accumulate);
+    OCRL_CHECK_LAUNCH("splitk_reduce");
+    return 0;
+}

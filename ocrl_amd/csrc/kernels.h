@@ -1,0 +1,149 @@
+// Internal launcher declarations shared by the kernel translation units, the model
+// orchestration (slate_model.cpp) and the C ABI (capi.cpp).  Not part of the public ABI.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------ gemm.hip
+struct GemmArgs {
+    const float* A = nullptr;
+    const float* B = nullptr;
+    float* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldb = 0, ldc = 0;
+    int akc = 1, bkc = 1;                 // operand storage, see gemm.hip
+    int batch = 1;                        // total batches; batch index z -> (z / batch_inner, z % batch_inner)
+    int batch_inner = 1;
+    long long sA = 0, sB = 0, sC = 0;     // outer batch strides (elements)
+    long long sAi = 0, sBi = 0, sCi = 0;  // inner batch strides (e.g. attention heads inside a [B,T,d] tensor)
+    int splitk = 1;
+    long long sCsplit = 0;                // slab stride when splitk > 1 (raw alpha*acc partials)
+    // epilogue (ignored when splitk > 1):  v = alpha*acc + bias[n]; relu; dropout; *(mask>0); + resid
+    float alpha = 1.f;
+    const float* bias = nullptr;
+    int relu = 0;
+    float drop_p = 0.f;
+    unsigned long long drop_seed = 0;
+    unsigned drop_site = 0;
+    const float* mask = nullptr; int ldmask = 0; long long sMask = 0;
+    const float* resid = nullptr; int ldr = 0; long long sR = 0;
+};
+int gemm_launch(const GemmArgs& a, hipStream_t st);
+int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
+                         int accumulate, hipStream_t st);
+
+// ------------------------------------------------------------------ conv.hip
+struct ConvArgs {
+    const float* X = nullptr;       // [B,H,W,CIN] NHWC
+    const float* Wp = nullptr;      // packed weights [KS*KS][CIN/8][COUT][8]
+    float* Y = nullptr;             // [B,H,W,COUT]
+    int B = 0, H = 0, W = 0;
+    const float* bias = nullptr;    // [COUT]
+    int relu = 0;
+    const float* posmap = nullptr;  // [H,W,COUT] added after bias/relu
+    const float* mask = nullptr;    // [B,H,W,COUT]: output zeroed where mask <= 0 (ReLU backward)
+};
+struct WgradArgs {
+    const float* X = nullptr;       // [B,H,W,CIN]
+    const float* dY = nullptr;      // [B,H,W,COUT]
+    float* part = nullptr;          // workspace, conv_wgrad_ws_floats()
+    int B = 0, H = 0, W = 0;
+};
+int conv_fwd_launch(const ConvArgs& a, int KS, int CIN, int COUT, hipStream_t st);
+int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st);
+size_t conv_wgrad_ws_floats(int B, int H, int W, int KS, int CIN);
+int conv_pack_launch(const float* W, float* fwd, float* bwd, int KS, int CIN, int COUT, int cin_real, hipStream_t st);
+
+// ------------------------------------------------------------------ elementwise.hip
+int nchw_to_nhwc8_launch(const float* in, float* out, int B, int C, int H, int W, hipStream_t st);
+int patchify4_launch(const float* in, float* out, int B, int C, int S, hipStream_t st);
+int pixel_shuffle_launch(const float* in, float* out, int B, int h, int w, int Cout, int forward, const float* mask, hipStream_t st);
+int layernorm_fwd_launch(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, long long R, int F, hipStream_t st);
+int layernorm_bwd_launch(const float* dy, const float* x, const float* mean, const float* rstd, const float* g, float* dx,
+                         float* dgb, long long R, int F, int accumulate_dx, int accumulate_dgb, float* ws, size_t ws_floats, hipStream_t st);
+int colsum_launch(const float* X, long long ld, float* out, long long R, int F, int accumulate, float scale, float* ws, size_t ws_floats, hipStream_t st);
+int reduce_partials_launch(const float* part, int n, float* out, float scale, int accumulate, hipStream_t st);
+int mse_launch(const float* obs, const float* recon, float* drecon, float* out, int B, int C, int H, int W, float* ws, size_t ws_floats, hipStream_t st);
+int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, float* z, int* tokens, long long R, int V, float tau,
+                          unsigned long long seed, hipStream_t st);
+int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st);
+int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st);
+int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,
+                     unsigned long long seed, hipStream_t st);
+int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int d, float p, unsigned long long seed, hipStream_t st);
+int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
+int dropout_mask_launch(float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
+int softmax_causal_fwd_launch(float* S, float* Pd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st);
+int softmax_causal_bwd_launch(const float* P, float* dPd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st);
+int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, float* O, float* P, int B, int T, int K, int d, int h, float p,
+                          unsigned long long seed, unsigned site, hipStream_t st);
+int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
+                          int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st);
+int fill_launch(float* x, long long n, float v, hipStream_t st);
+int axpy_launch(const float* x, float* y, long long n, float a, hipStream_t st);
+int posmap_launch(const float* Wpos, const float* bpos, float* out, int S, int C, hipStream_t st);
+int posgrid_launch(float* out, int S, hipStream_t st);
+int pad_cols_launch(const float* in, int ldi, float* out, int ldo, long long R, int C, int Cout, hipStream_t st);
+
+// ------------------------------------------------------------------ slot_attn.hip
+// Packed weight block (built once per step by pack_launch): originals and transposed copies.
+struct SaWts {
+    int ln_in_g, ln_in_b, ln_s_g, ln_s_b, ln_m_g, ln_m_b;
+    int Wq, WqT, Wk, WkT, Wv, WvT, Wih, WihT, Whh, WhhT, bih, bhh, W0, W0T, b0, W2, W2T, b2;
+    int total;
+};
+static inline SaWts sa_wts_layout(int C, int D, int H) {
+    SaWts o; int a = 0;
+    auto take = [&](int n) { int r = a; a += (n + 3) & ~3; return r; };
+    o.ln_in_g = take(C); o.ln_in_b = take(C); o.ln_s_g = take(D); o.ln_s_b = take(D); o.ln_m_g = take(D); o.ln_m_b = take(D);
+    o.Wq = take(D * D); o.WqT = take(D * D); o.Wk = take(D * C); o.WkT = take(C * D); o.Wv = take(D * C); o.WvT = take(C * D);
+    o.Wih = take(3 * D * D); o.WihT = take(3 * D * D); o.Whh = take(3 * D * D); o.WhhT = take(3 * D * D);
+    o.bih = take(3 * D); o.bhh = take(3 * D);
+    o.W0 = take(H * D); o.W0T = take(H * D); o.b0 = take(H); o.W2 = take(D * H); o.W2T = take(D * H); o.b2 = take(D);
+    o.total = a;
+    return o;
+}
+// Saved-activation matrix: one row per (image, iteration, slot), row = (b*I + t)*K + j, fields at fixed
+// column offsets, so every field is a strided [B*I*K, dim] GEMM operand with ld = sa_save_ld().
+struct SaSave { int sprev, sn, q, u, r, z, n, hn, sg, m, hid, qp, up, csum, ld; };
+static inline SaSave sa_save_layout(int C, int D, int H) {
+    SaSave o;
+    o.sprev = 0; o.sn = D; o.q = 2 * D; o.u = 3 * D; o.r = 4 * D; o.z = 5 * D; o.n = 6 * D; o.hn = 7 * D; o.sg = 8 * D; o.m = 9 * D;
+    o.hid = 10 * D; o.qp = 10 * D + H; o.up = 10 * D + H + C; o.csum = 10 * D + H + 2 * C; o.ld = 10 * D + H + 2 * C + 4;
+    return o;
+}
+// Gradient rows emitted by the backward kernel (same row index), consumed by the weight-gradient GEMMs.
+struct SaGrad { int out, hid, gi, gh, u, q, qp, ld; };
+static inline SaGrad sa_grad_layout(int C, int D, int H) {
+    SaGrad o;
+    o.out = 0; o.hid = D; o.gi = D + H; o.gh = 4 * D + H; o.u = 7 * D + H; o.q = 8 * D + H; o.qp = 9 * D + H; o.ld = 9 * D + H + C;
+    return o;
+}
+struct SlotAttnArgs {
+    int B = 0, N = 0, C = 64, K = 0, D = 0, H = 0, I = 0;
+    float eps = 1e-8f, scale = 1.f;
+    const float* x = nullptr;        // [B,N,C]
+    const float* slots0 = nullptr;   // [B,K,D]
+    const float* wts = nullptr;      // packed weights, sa_wts_layout
+    float* slots = nullptr;          // [B,K,D]
+    float* attn = nullptr;           // [B,N,K] (last iteration, pre-eps), may be null
+    float* save = nullptr;           // [B*I*K, sa_save_layout().ld], may be null for inference
+    const float* dslots = nullptr;   // [B,K,D]
+    float* dx = nullptr;             // [B,N,C]
+    float* dslots0 = nullptr;        // [B,K,D]
+    float* grows = nullptr;          // [B*I*K, sa_grad_layout().ld]
+    float* g_small = nullptr;        // [B][4D + 2C]: dgamma/dbeta of norm_slots, norm_mlp, norm_inputs
+};
+int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st);
+
+// generic gather/transposing pack: entry e copies src[rows][cols] to dst + dst_off (transposed if requested)
+struct PackEntry { const float* src; int rows, cols, dst_off, transpose; };
+int pack_launch(const PackEntry* entries_dev, int n_entries, int max_elems, float* dst, hipStream_t st);
+
+// ------------------------------------------------------------------ optim.hip
+int absmax_launch(const float* g, long long n, float* out, float* ws, size_t ws_floats, hipStream_t st);
+// g is first scaled by gscale (1/world for data parallel mean), then clipped by the inf-norm in norm[0]*gscale
+int clip_adam_launch(float* p, const float* g, float* m, float* v, long long n, const float* norm, float clip, float lr, float b1,
+                     float b2, float eps, int step, float gscale, hipStream_t st);
+int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st);
+int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float* noise, float* dmu, float* dlogsig, int BK, int D, unsigned long long seed, hipStream_t st);
+int copy_launch(const float* src, float* dst, long long n, hipStream_t st);

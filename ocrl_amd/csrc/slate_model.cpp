@@ -1,0 +1,672 @@
+// SLATE training step on the HIP kernels: parameter table, workspace, forward, backward, optimiser.
+// Follows the reference's SLATE_Module.get_loss (ocrs/slate/slate_module.py:198-241) and
+// Base.update (ocrs/base.py:60-74); maths restated in SURVEY.md Appendix A.
+#include "slate_model.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#define RC(x)                 \
+    do {                      \
+        int rc__ = (x);       \
+        if (rc__) return rc__; \
+    } while (0)
+
+static std::string fmt(const char* f, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof buf, f, ap);
+    va_end(ap);
+    return buf;
+}
+
+// ---------------------------------------------------------------------------------------------
+SlateModel::SlateModel(const SlateConfig& c) : cfg(c) {
+    S = c.obs_size; E = S / 4; T = E * E; N = S * S; V = c.vocab; d = c.d_model; C = c.cnn_hidden;
+    K = c.num_slots; I = c.num_iters; D = c.slot_size; H = c.mlp_hidden; NB = c.num_blocks; NH = c.num_heads;
+    DH = d / NH; Bmax = c.max_batch;
+    const int ch = c.obs_channels;
+    auto add = [&](const std::string& name, std::vector<int> shp, int g) {
+        ParamInfo p;
+        p.name = name; p.ndim = (int)shp.size(); p.group = g; p.numel = 1;
+        for (size_t i = 0; i < shp.size(); ++i) { p.shape[i] = shp[i]; p.numel *= shp[i]; }
+        params_.push_back(p);
+    };
+    // group 0: dVAE (ocrs/common/models.py:10-37) — order = reference module.parameters() order
+    add("_dvae._encoder.0.m.weight", {64, ch, 4, 4}, 0); add("_dvae._encoder.0.m.bias", {64}, 0);
+    for (int i = 1; i < 7; ++i) { add(fmt("_dvae._encoder.%d.m.weight", i), {64, 64, 1, 1}, 0); add(fmt("_dvae._encoder.%d.m.bias", i), {64}, 0); }
+    add("_dvae._encoder.7.weight", {V, 64, 1, 1}, 0); add("_dvae._encoder.7.bias", {V}, 0);
+    const int di[9] = {0, 1, 2, 3, 4, 6, 7, 8, 9};
+    const int dshape[9][4] = {{64, V, 1, 1}, {64, 64, 3, 3}, {64, 64, 1, 1}, {64, 64, 1, 1}, {256, 64, 1, 1},
+                              {64, 64, 3, 3}, {64, 64, 1, 1}, {64, 64, 1, 1}, {256, 64, 1, 1}};
+    for (int i = 0; i < 9; ++i) {
+        add(fmt("_dvae._decoder.%d.m.weight", di[i]), {dshape[i][0], dshape[i][1], dshape[i][2], dshape[i][3]}, 0);
+        add(fmt("_dvae._decoder.%d.m.bias", di[i]), {dshape[i][0]}, 0);
+    }
+    add("_dvae._decoder.11.weight", {ch, 64, 1, 1}, 0); add("_dvae._decoder.11.bias", {ch}, 0);
+    // group 1
+    add("_enc._encoder.0.m.weight", {C, ch, 5, 5}, 1); add("_enc._encoder.0.m.bias", {C}, 1);
+    for (int i = 1; i < 3; ++i) { add(fmt("_enc._encoder.%d.m.weight", i), {C, C, 5, 5}, 1); add(fmt("_enc._encoder.%d.m.bias", i), {C}, 1); }
+    add("_enc._encoder.3.weight", {C, C, 5, 5}, 1); add("_enc._encoder.3.bias", {C}, 1);
+    add("_enc_pos.channels_map.weight", {C, 4, 1, 1}, 1); add("_enc_pos.channels_map.bias", {C}, 1);
+    add("_slotattn.slot_mu", {1, 1, D}, 1); add("_slotattn.slot_log_sigma", {1, 1, D}, 1);
+    add("_slotattn.layer_norm.weight", {C}, 1); add("_slotattn.layer_norm.bias", {C}, 1);
+    add("_slotattn.mlp.0.weight", {C, C}, 1); add("_slotattn.mlp.0.bias", {C}, 1);
+    add("_slotattn.mlp.2.weight", {C, C}, 1); add("_slotattn.mlp.2.bias", {C}, 1);
+    const std::string sa = "_slotattn.slot_attention.";
+    add(sa + "norm_inputs.weight", {C}, 1); add(sa + "norm_inputs.bias", {C}, 1);
+    add(sa + "norm_slots.weight", {D}, 1); add(sa + "norm_slots.bias", {D}, 1);
+    add(sa + "norm_mlp.weight", {D}, 1); add(sa + "norm_mlp.bias", {D}, 1);
+    add(sa + "project_q.weight", {D, D}, 1); add(sa + "project_k.weight", {D, C}, 1); add(sa + "project_v.weight", {D, C}, 1);
+    add(sa + "gru.weight_ih", {3 * D, D}, 1); add(sa + "gru.weight_hh", {3 * D, D}, 1);
+    add(sa + "gru.bias_ih", {3 * D}, 1); add(sa + "gru.bias_hh", {3 * D}, 1);
+    add(sa + "mlp.0.weight", {H, D}, 1); add(sa + "mlp.0.bias", {H}, 1);
+    add(sa + "mlp.2.weight", {D, H}, 1); add(sa + "mlp.2.bias", {D}, 1);
+    add("_slotproj.weight", {d, D}, 1);
+    // group 2
+    add("_dict.dictionary.weight", {V, d}, 2);
+    add("_bos_token._bos_token", {1, 1, d}, 2);
+    add("_z_pos.pe", {1, 1 + T, d}, 2);
+    for (int b = 0; b < NB; ++b) {
+        const std::string p = fmt("_tfdec.blocks.%d.", b);
+        add(p + "self_attn_layer_norm.weight", {d}, 2); add(p + "self_attn_layer_norm.bias", {d}, 2);
+        for (const char* q : {"q", "k", "v", "o"}) add(p + "self_attn.proj_" + q + ".weight", {d, d}, 2);
+        add(p + "encoder_decoder_attn_layer_norm.weight", {d}, 2); add(p + "encoder_decoder_attn_layer_norm.bias", {d}, 2);
+        for (const char* q : {"q", "k", "v", "o"}) add(p + "encoder_decoder_attn.proj_" + q + ".weight", {d, d}, 2);
+        add(p + "ffn_layer_norm.weight", {d}, 2); add(p + "ffn_layer_norm.bias", {d}, 2);
+        add(p + "ffn.0.weight", {4 * d, d}, 2); add(p + "ffn.0.bias", {4 * d}, 2);
+        add(p + "ffn.2.weight", {d, 4 * d}, 2); add(p + "ffn.2.bias", {d}, 2);
+    }
+    add("_tfdec.layer_norm.weight", {d}, 2); add("_tfdec.layer_norm.bias", {d}, 2);
+    add("_out.weight", {V, d}, 2);
+
+    long long off = 0;
+    int g = 0;
+    group_begin_[0] = 0;
+    for (size_t i = 0; i < params_.size(); ++i) {
+        while (g < params_[i].group) group_begin_[++g] = off;
+        params_[i].offset = off;
+        off += (params_[i].numel + 3) & ~3ll;       // keep every tensor 16-byte aligned (float4 / MFMA staging)
+        index_[params_[i].name] = (int)i;
+    }
+    while (g < 3) group_begin_[++g] = off;
+    flat_size_ = off;
+    blk_.resize(NB);
+    layout_workspace(false);
+}
+
+float* SlateModel::P(const std::string& n) const { return p_ + params_[index_.at(n)].offset; }
+float* SlateModel::G(const std::string& n) const { return g_ + params_[index_.at(n)].offset; }
+
+float* SlateModel::carve(const char* name, size_t n) {
+    const size_t bytes = (n * 4 + 255) & ~(size_t)255;
+    float* p = reinterpret_cast<float*>(ws_ + ws_off_);
+    ws_off_ += bytes;
+    if (ws_commit_ && name) named_[name] = std::make_pair(p, n);
+    return p;
+}
+
+void SlateModel::layout_workspace(bool commit) {
+    ws_commit_ = commit;
+    ws_off_ = 0;
+    const size_t B = Bmax, BT = B * T, BN = B * N, BK = B * K;
+    metrics_ = carve("metrics", 64);
+    // transient scratch: split-k slabs (<= 1024 slabs of the largest weight tile set), wgrad slabs, column sums
+    scratch_floats_ = 0;
+    {
+        size_t need = conv_wgrad_ws_floats((int)B, S, S, 5, 64);
+        size_t sk = (size_t)16 * V * d + (size_t)(1 << 20);        // split-k slabs for the [V,d] weights
+        if (sk > need) need = sk;
+        size_t cs = (size_t)N * C * 8 + (size_t)T * d * 8 + (1 << 20);   // column-sum partials (pos map / pe)
+        if (cs > need) need = cs;
+        scratch_floats_ = need + (1 << 20);
+    }
+    scratch_ = carve(nullptr, scratch_floats_);
+    obs8_ = carve("obs8", BN * 8);
+    patches_ = carve("patches", BT * 16 * cfg.obs_channels);
+    for (int i = 0; i < 7; ++i) de_[i] = carve(nullptr, BT * 64);
+    zraw_ = carve("zraw", BT * V);
+    z_ = carve("z", BT * V);
+    tokens_ = reinterpret_cast<int*>(carve("tokens", BT));
+    dd0_ = carve(nullptr, BT * 64); dd1_ = carve(nullptr, BT * 64); dd2_ = carve(nullptr, BT * 64); dd3_ = carve(nullptr, BT * 64);
+    dd4_ = carve(nullptr, BT * 256); ps1_ = carve(nullptr, BT * 256);
+    dd6_ = carve(nullptr, BT * 256); dd7_ = carve(nullptr, BT * 256); dd8_ = carve(nullptr, BT * 256);
+    dd9_ = carve(nullptr, BT * 1024); ps2_ = carve(nullptr, BN * 64);
+    recon_ = carve("recon", BN * 4); drecon_ = carve(nullptr, BN * 4);
+    e1_ = carve(nullptr, BN * 64); e2_ = carve(nullptr, BN * 64); e3_ = carve(nullptr, BN * 64); e4_ = carve("feats", BN * 64);
+    posmap_ = carve(nullptr, (size_t)N * C); gridT_ = carve(nullptr, (size_t)N * 4);
+    ln0_ = carve(nullptr, BN * 64); ln0_mean_ = carve(nullptr, BN); ln0_rstd_ = carve(nullptr, BN);
+    h1_ = carve(nullptr, BN * 64); x_ = carve("sa_inputs", BN * 64);
+    slots0_ = carve("slots0", BK * D); slot_noise_ = carve(nullptr, BK * D); slots_ = carve("slots", BK * D);
+    attn_ = carve("attn", BN * K);
+    const SaSave so = sa_save_layout(C, D, H);
+    const SaGrad go = sa_grad_layout(C, D, H);
+    const SaWts wo = sa_wts_layout(C, D, H);
+    sa_save_ = carve(nullptr, BK * I * so.ld);
+    sa_grows_ = carve(nullptr, BK * I * go.ld);
+    sa_wts_ = carve(nullptr, wo.total);
+    sa_small_ = carve(nullptr, B * (4 * D + 2 * C));
+    sa_pack_dev_ = reinterpret_cast<PackEntry*>(carve(nullptr, 64 * sizeof(PackEntry) / 4 + 64));
+    for (int i = 0; i < 4; ++i) {
+        const int cin = i == 0 ? 8 : 64;
+        cw_fwd_[i] = carve(nullptr, (size_t)25 * cin * 64);
+        cw_bwd_[i] = i == 0 ? nullptr : carve(nullptr, (size_t)25 * 64 * 64);
+    }
+    for (int i = 0; i < 2; ++i) { dw_fwd_[i] = carve(nullptr, 9 * 64 * 64); dw_bwd_[i] = carve(nullptr, 9 * 64 * 64); }
+    w11p_ = carve(nullptr, 4 * 64);
+    mem_ = carve("mem", BK * d); emb_ = carve("emb", BT * d);
+    const size_t att = B * NH * (size_t)T * T;
+    for (int b = 0; b < NB; ++b) {
+        Blk& k = blk_[b];
+        k.ln1 = carve(nullptr, BT * d); k.ln1_mean = carve(nullptr, BT); k.ln1_rstd = carve(nullptr, BT);
+        k.q = carve(nullptr, BT * d); k.k = carve(nullptr, BT * d); k.v = carve(nullptr, BT * d);
+        k.P = carve(nullptr, att); k.ao = carve(nullptr, BT * d); k.x1 = carve(nullptr, BT * d);
+        k.ln2 = carve(nullptr, BT * d); k.ln2_mean = carve(nullptr, BT); k.ln2_rstd = carve(nullptr, BT);
+        k.cq = carve(nullptr, BT * d); k.ck = carve(nullptr, BK * d); k.cv = carve(nullptr, BK * d);
+        k.cP = carve(nullptr, B * NH * (size_t)T * K); k.cao = carve(nullptr, BT * d); k.x2 = carve(nullptr, BT * d);
+        k.ln3 = carve(nullptr, BT * d); k.ln3_mean = carve(nullptr, BT); k.ln3_rstd = carve(nullptr, BT);
+        k.f1 = carve(nullptr, BT * 4 * d); k.x3 = carve(nullptr, BT * d);
+    }
+    Pd_ = carve(nullptr, att); dP_ = carve(nullptr, att);
+    lnf_ = carve("dec_out", BT * d); lnf_mean_ = carve(nullptr, BT); lnf_rstd_ = carve(nullptr, BT);
+    pred_ = carve("pred", BT * V);
+    gx_ = carve(nullptr, BT * d); gbr_ = carve(nullptr, BT * d); gt1_ = carve(nullptr, BT * d); gt2_ = carve(nullptr, BT * d);
+    gt3_ = carve(nullptr, BT * d); gf1_ = carve(nullptr, BT * 4 * d);
+    gmem_ = carve(nullptr, BK * d); gck_ = carve(nullptr, BK * d); gcv_ = carve(nullptr, BK * d);
+    gslots_ = carve(nullptr, BK * D); gslots0_ = carve(nullptr, BK * D);
+    gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64);
+    gdA_ = carve(nullptr, BN * 64); gdB_ = carve(nullptr, BN * 64);
+    gmap_ = carve(nullptr, (size_t)N * C);
+    if (!commit) ws_bytes_ = ws_off_ + 4096;
+}
+
+int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws_bytes) {
+    OCRL_REQUIRE(p && g && ws, "bind: null buffer");
+    OCRL_REQUIRE(ws_bytes >= ws_bytes_, "bind: workspace too small (%zu < %zu)", ws_bytes, ws_bytes_);
+    OCRL_REQUIRE(((uintptr_t)p & 255) == 0 && ((uintptr_t)g & 255) == 0 && ((uintptr_t)ws & 255) == 0, "bind: buffers must be 256-byte aligned");
+    OCRL_REQUIRE(d % 64 == 0 && d <= 256 && D % 64 == 0 && C == 64 && V % 256 == 0 && S % 4 == 0 && d % NH == 0 && DH % 4 == 0 && DH <= 64,
+                 "unsupported configuration (d_model/slot_size multiples of 64 <= 256, cnn hidden 64, vocab %% 256, obs_size %% 4)");
+    OCRL_REQUIRE(cfg.obs_channels == 3, "obs_channels must be 3");
+    OCRL_REQUIRE(T % 4 == 0, "obs_size/4 squared must be a multiple of 4");
+    p_ = p; g_ = g; m_ = m; v_ = v;
+    ws_ = static_cast<char*>(ws);
+    named_.clear();
+    layout_workspace(true);
+    // static tables
+    RC(posgrid_launch(gridT_, S, 0));
+    RC(fill_launch(recon_, (long long)Bmax * N * 4, 0.f, 0));
+    // slot-attention weight pack table
+    const SaWts wo = sa_wts_layout(C, D, H);
+    const std::string sa = "_slotattn.slot_attention.";
+    std::vector<PackEntry> ent;
+    auto e = [&](const std::string& name, int rows, int cols, int off, int tr) {
+        PackEntry x; x.src = P(name); x.rows = rows; x.cols = cols; x.dst_off = off; x.transpose = tr;
+        ent.push_back(x);
+    };
+    e(sa + "norm_inputs.weight", 1, C, wo.ln_in_g, 0); e(sa + "norm_inputs.bias", 1, C, wo.ln_in_b, 0);
+    e(sa + "norm_slots.weight", 1, D, wo.ln_s_g, 0); e(sa + "norm_slots.bias", 1, D, wo.ln_s_b, 0);
+    e(sa + "norm_mlp.weight", 1, D, wo.ln_m_g, 0); e(sa + "norm_mlp.bias", 1, D, wo.ln_m_b, 0);
+    e(sa + "project_q.weight", D, D, wo.Wq, 0); e(sa + "project_q.weight", D, D, wo.WqT, 1);
+    e(sa + "project_k.weight", D, C, wo.Wk, 0); e(sa + "project_k.weight", D, C, wo.WkT, 1);
+    e(sa + "project_v.weight", D, C, wo.Wv, 0); e(sa + "project_v.weight", D, C, wo.WvT, 1);
+    e(sa + "gru.weight_ih", 3 * D, D, wo.Wih, 0); e(sa + "gru.weight_ih", 3 * D, D, wo.WihT, 1);
+    e(sa + "gru.weight_hh", 3 * D, D, wo.Whh, 0); e(sa + "gru.weight_hh", 3 * D, D, wo.WhhT, 1);
+    e(sa + "gru.bias_ih", 1, 3 * D, wo.bih, 0); e(sa + "gru.bias_hh", 1, 3 * D, wo.bhh, 0);
+    e(sa + "mlp.0.weight", H, D, wo.W0, 0); e(sa + "mlp.0.weight", H, D, wo.W0T, 1); e(sa + "mlp.0.bias", 1, H, wo.b0, 0);
+    e(sa + "mlp.2.weight", D, H, wo.W2, 0); e(sa + "mlp.2.weight", D, H, wo.W2T, 1); e(sa + "mlp.2.bias", 1, D, wo.b2, 0);
+    sa_pack_n_ = (int)ent.size();
+    sa_pack_max_ = 3 * D * D;
+    OCRL_REQUIRE(sa_pack_n_ <= 64, "pack table overflow");
+    OCRL_HIP(hipMemcpy(sa_pack_dev_, ent.data(), ent.size() * sizeof(PackEntry), hipMemcpyHostToDevice));
+    OCRL_HIP(hipDeviceSynchronize());
+    have_fwd_ = false;
+    return 0;
+}
+
+int SlateModel::tensor(const char* name, float** ptr, long long* count) const {
+    auto it = named_.find(name);
+    if (it == named_.end()) {
+        auto pi = index_.find(name);
+        OCRL_REQUIRE(pi != index_.end(), "tensor: unknown name '%s'", name);
+        *ptr = p_ + params_[pi->second].offset;
+        *count = params_[pi->second].numel;
+        return 0;
+    }
+    *ptr = it->second.first;
+    *count = (long long)it->second.second;
+    return 0;
+}
+
+int SlateModel::dropout_mask(unsigned site, long long n, float* out, hipStream_t st) const {
+    return dropout_mask_launch(out, n, pdrop_, last_.seed, site, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+int SlateModel::lin_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, long long M, int Nn, int Kk, int relu,
+                        const float* resid, int ldr, float drop_p, unsigned site, hipStream_t st) {
+    GemmArgs a;
+    a.A = x; a.B = W; a.C = y; a.M = (int)M; a.N = Nn; a.K = Kk; a.lda = ldx; a.ldb = Kk; a.ldc = ldy; a.akc = 1; a.bkc = 1;
+    a.bias = b; a.relu = relu; a.resid = resid; a.ldr = ldr; a.drop_p = drop_p; a.drop_seed = last_.seed; a.drop_site = site;
+    return gemm_launch(a, st);
+}
+// dx[M,K_in] = (dy[M,N_out] W[N_out,K_in]) * (mask > 0) + resid
+int SlateModel::lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx, int ldx, long long M, int N_out, int K_in,
+                          const float* mask, int ldmask, const float* resid, int ldr, hipStream_t st) {
+    GemmArgs a;
+    a.A = dy; a.B = W; a.C = dx; a.M = (int)M; a.N = K_in; a.K = N_out; a.lda = ld_dy; a.ldb = K_in; a.ldc = ldx; a.akc = 1; a.bkc = 0;
+    a.mask = mask; a.ldmask = ldmask; a.resid = resid; a.ldr = ldr;
+    return gemm_launch(a, st);
+}
+// dW[N_out,K_in] = alpha * dy^T x (split over the M rows);  db[N_out] = column sums of dy
+int SlateModel::lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in,
+                          float alpha, hipStream_t st) {
+    GemmArgs a;
+    a.A = dy; a.B = x; a.C = dW; a.M = N_out; a.N = K_in; a.K = (int)M; a.lda = ld_dy; a.ldb = ldx; a.ldc = K_in; a.akc = 0; a.bkc = 0;
+    a.alpha = alpha;
+    const int tiles = cdiv(N_out, 128) * cdiv(K_in, K_in > 64 ? 128 : 64);
+    long long splits = 1024 / tiles;
+    if (splits > M / 256) splits = M / 256;
+    if (splits < 1) splits = 1;
+    const long long slab = (long long)N_out * K_in;
+    if (splits * slab > (long long)scratch_floats_) splits = (long long)scratch_floats_ / slab;
+    if (splits > 1) {
+        a.splitk = (int)splits; a.C = scratch_; a.sCsplit = slab;
+        RC(gemm_launch(a, st));
+        RC(splitk_reduce_launch(scratch_, dW, slab, (int)splits, slab, 0, st));
+    } else {
+        RC(gemm_launch(a, st));
+    }
+    if (db) RC(colsum_launch(dy, ld_dy, db, M, N_out, 0, 1.f, scratch_, scratch_floats_, st));
+    return 0;
+}
+int SlateModel::conv_layer_fwd(const float* x, const float* pack, const float* bias, float* y, int Bn, int Hh, int Ww, int KS, int CIN,
+                               int relu, const float* posmap, const float* mask, hipStream_t st) {
+    ConvArgs a;
+    a.X = x; a.Wp = pack; a.Y = y; a.B = Bn; a.H = Hh; a.W = Ww; a.bias = bias; a.relu = relu; a.posmap = posmap; a.mask = mask;
+    return conv_fwd_launch(a, KS, CIN, 64, st);
+}
+int SlateModel::conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN,
+                                 int cin_real, hipStream_t st) {
+    WgradArgs a;
+    a.X = x; a.dY = dy; a.part = scratch_; a.B = Bn; a.H = Hh; a.W = Ww;
+    OCRL_REQUIRE(conv_wgrad_ws_floats(Bn, Hh, Ww, KS, CIN) <= scratch_floats_, "conv wgrad: scratch too small");
+    RC(conv_wgrad_launch(a, KS, CIN, 64, cin_real, dW, 0, st));
+    if (db) RC(colsum_launch(dy, 64, db, (long long)Bn * Hh * Ww, 64, 0, 1.f, scratch_, scratch_floats_, st));
+    return 0;
+}
+
+int SlateModel::pack_weights(hipStream_t st) {
+    RC(conv_pack_launch(P("_enc._encoder.0.m.weight"), cw_fwd_[0], nullptr, 5, 8, 64, cfg.obs_channels, st));
+    RC(conv_pack_launch(P("_enc._encoder.1.m.weight"), cw_fwd_[1], cw_bwd_[1], 5, 64, 64, 64, st));
+    RC(conv_pack_launch(P("_enc._encoder.2.m.weight"), cw_fwd_[2], cw_bwd_[2], 5, 64, 64, 64, st));
+    RC(conv_pack_launch(P("_enc._encoder.3.weight"), cw_fwd_[3], cw_bwd_[3], 5, 64, 64, 64, st));
+    RC(conv_pack_launch(P("_dvae._decoder.1.m.weight"), dw_fwd_[0], dw_bwd_[0], 3, 64, 64, 64, st));
+    RC(conv_pack_launch(P("_dvae._decoder.6.m.weight"), dw_fwd_[1], dw_bwd_[1], 3, 64, 64, 64, st));
+    RC(copy_launch(P("_dvae._decoder.11.weight"), w11p_, cfg.obs_channels * 64, st));    // [3,64] -> [4,64], row 3 zero
+    RC(fill_launch(w11p_ + cfg.obs_channels * 64, (4 - cfg.obs_channels) * 64, 0.f, st));
+    RC(pack_launch(sa_pack_dev_, sa_pack_n_, sa_pack_max_, sa_wts_, st));
+    RC(posmap_launch(P("_enc_pos.channels_map.weight"), P("_enc_pos.channels_map.bias"), posmap_, S, C, st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CNN encoder + slot attention (ocrs/common/models.py:96-107, slot_attn.py:147-161)
+int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st) {
+    const int B = in.B;
+    const long long BN = (long long)B * N;
+    RC(nchw_to_nhwc8_launch(in.obs, obs8_, B, cfg.obs_channels, S, S, st));
+    RC(conv_layer_fwd(obs8_, cw_fwd_[0], P("_enc._encoder.0.m.bias"), e1_, B, S, S, 5, 8, 1, nullptr, nullptr, st));
+    RC(conv_layer_fwd(e1_, cw_fwd_[1], P("_enc._encoder.1.m.bias"), e2_, B, S, S, 5, 64, 1, nullptr, nullptr, st));
+    RC(conv_layer_fwd(e2_, cw_fwd_[2], P("_enc._encoder.2.m.bias"), e3_, B, S, S, 5, 64, 1, nullptr, nullptr, st));
+    RC(conv_layer_fwd(e3_, cw_fwd_[3], P("_enc._encoder.3.bias"), e4_, B, S, S, 5, 64, 0, posmap_, nullptr, st));
+    RC(layernorm_fwd_launch(e4_, P("_slotattn.layer_norm.weight"), P("_slotattn.layer_norm.bias"), ln0_, ln0_mean_, ln0_rstd_, BN, C, st));
+    RC(lin_fwd(ln0_, C, P("_slotattn.mlp.0.weight"), P("_slotattn.mlp.0.bias"), h1_, C, BN, C, C, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(h1_, C, P("_slotattn.mlp.2.weight"), P("_slotattn.mlp.2.bias"), x_, C, BN, C, C, 0, nullptr, 0, 0.f, 0, st));
+    RC(slot_init_launch(P("_slotattn.slot_mu"), P("_slotattn.slot_log_sigma"), in.noise_slots, slots0_, B * K, D, in.seed, st));
+    SlotAttnArgs a;
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
+    a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
+    RC(slot_attn_launch(a, 0, st));
+    return 0;
+}
+
+// dVAE encode -> Gumbel softmax -> decode -> reconstruction loss (models.py:14-45, utils.py:75-85)
+int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
+    const int B = in.B;
+    const long long BT = (long long)B * T, BN = (long long)B * N;
+    const int ch = cfg.obs_channels;
+    RC(patchify4_launch(in.obs, patches_, B, ch, S, st));
+    RC(lin_fwd(patches_, 16 * ch, P("_dvae._encoder.0.m.weight"), P("_dvae._encoder.0.m.bias"), de_[0], 64, BT, 64, 16 * ch, 1, nullptr, 0, 0.f, 0, st));
+    for (int i = 1; i < 7; ++i)
+        RC(lin_fwd(de_[i - 1], 64, P(fmt("_dvae._encoder.%d.m.weight", i)), P(fmt("_dvae._encoder.%d.m.bias", i)), de_[i], 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(de_[6], 64, P("_dvae._encoder.7.weight"), P("_dvae._encoder.7.bias"), zraw_, V, BT, V, 64, 0, nullptr, 0, 0.f, 0, st));
+    RC(gumbel_softmax_launch(zraw_, in.noise_z, in.noise_zh, z_, tokens_, BT, V, in.tau, in.seed, st));
+    // decoder
+    RC(lin_fwd(z_, V, P("_dvae._decoder.0.m.weight"), P("_dvae._decoder.0.m.bias"), dd0_, 64, BT, 64, V, 1, nullptr, 0, 0.f, 0, st));
+    RC(conv_layer_fwd(dd0_, dw_fwd_[0], P("_dvae._decoder.1.m.bias"), dd1_, B, E, E, 3, 64, 1, nullptr, nullptr, st));
+    RC(lin_fwd(dd1_, 64, P("_dvae._decoder.2.m.weight"), P("_dvae._decoder.2.m.bias"), dd2_, 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(dd2_, 64, P("_dvae._decoder.3.m.weight"), P("_dvae._decoder.3.m.bias"), dd3_, 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(dd3_, 64, P("_dvae._decoder.4.m.weight"), P("_dvae._decoder.4.m.bias"), dd4_, 256, BT, 256, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(pixel_shuffle_launch(dd4_, ps1_, B, E, E, 64, 1, nullptr, st));
+    RC(conv_layer_fwd(ps1_, dw_fwd_[1], P("_dvae._decoder.6.m.bias"), dd6_, B, 2 * E, 2 * E, 3, 64, 1, nullptr, nullptr, st));
+    RC(lin_fwd(dd6_, 64, P("_dvae._decoder.7.m.weight"), P("_dvae._decoder.7.m.bias"), dd7_, 64, 4 * BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(dd7_, 64, P("_dvae._decoder.8.m.weight"), P("_dvae._decoder.8.m.bias"), dd8_, 64, 4 * BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(dd8_, 64, P("_dvae._decoder.9.m.weight"), P("_dvae._decoder.9.m.bias"), dd9_, 256, 4 * BT, 256, 64, 1, nullptr, 0, 0.f, 0, st));
+    RC(pixel_shuffle_launch(dd9_, ps2_, B, 2 * E, 2 * E, 64, 1, nullptr, st));
+    RC(lin_fwd(ps2_, 64, P("_dvae._decoder.11.weight"), P("_dvae._decoder.11.bias"), recon_, 4, BN, ch, 64, 0, nullptr, 0, 0.f, 0, st));
+    RC(mse_launch(in.obs, recon_, drecon_, metrics_ + 0, B, ch, S, S, scratch_, scratch_floats_, st));
+    return 0;
+}
+
+// token embedding + transformer decoder + cross entropy (slate_module.py:141-156, transformer.py)
+int SlateModel::fwd_decoder(hipStream_t st) {
+    const int B = last_.B;
+    const long long BT = (long long)B * T;
+    const float p = pdrop_;
+    const float scale = 1.0f / sqrtf((float)DH);
+    RC(lin_fwd(slots_, D, P("_slotproj.weight"), nullptr, mem_, d, (long long)B * K, d, D, 0, nullptr, 0, 0.f, 0, st));
+    RC(embed_fwd_launch(tokens_, P("_dict.dictionary.weight"), P("_bos_token._bos_token"), P("_z_pos.pe"), emb_, B, T, d, p, last_.seed, st));
+    const float* xin = emb_;
+    for (int b = 0; b < NB; ++b) {
+        Blk& k = blk_[b];
+        const std::string pre = fmt("_tfdec.blocks.%d.", b);
+        const unsigned site = SITE_BLK_BASE + 8 * b;
+        RC(layernorm_fwd_launch(xin, P(pre + "self_attn_layer_norm.weight"), P(pre + "self_attn_layer_norm.bias"), k.ln1, k.ln1_mean, k.ln1_rstd, BT, d, st));
+        const float* res = (b == 0) ? k.ln1 : xin;      // block 0 normalises the residual stream itself (transformer.py:175-178)
+        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_q.weight"), nullptr, k.q, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_k.weight"), nullptr, k.k, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_v.weight"), nullptr, k.v, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
+        {   // scores = (q * dh^-0.5) k^T per (image, head)
+            GemmArgs a;
+            a.A = k.q; a.B = k.k; a.C = k.P; a.M = T; a.N = T; a.K = DH; a.lda = d; a.ldb = d; a.ldc = T; a.akc = 1; a.bkc = 1;
+            a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)T * d; a.sAi = DH; a.sB = (long long)T * d; a.sBi = DH;
+            a.sC = (long long)NH * T * T; a.sCi = (long long)T * T; a.alpha = scale;
+            RC(gemm_launch(a, st));
+        }
+        float* Pd = p > 0.f ? Pd_ : k.P;
+        RC(softmax_causal_fwd_launch(k.P, Pd, (long long)B * NH, T, p, last_.seed, site + 0, st));
+        {   // ao = dropout(P) v
+            GemmArgs a;
+            a.A = Pd; a.B = k.v; a.C = k.ao; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 1; a.bkc = 0;
+            a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
+            a.sC = (long long)T * d; a.sCi = DH;
+            RC(gemm_launch(a, st));
+        }
+        RC(lin_fwd(k.ao, d, P(pre + "self_attn.proj_o.weight"), nullptr, k.x1, d, BT, d, d, 0, res, d, p, site + 1, st));
+        // cross attention to the projected slots
+        RC(layernorm_fwd_launch(k.x1, P(pre + "encoder_decoder_attn_layer_norm.weight"), P(pre + "encoder_decoder_attn_layer_norm.bias"), k.ln2, k.ln2_mean, k.ln2_rstd, BT, d, st));
+        RC(lin_fwd(k.ln2, d, P(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, k.cq, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(lin_fwd(mem_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, k.ck, d, (long long)B * K, d, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(lin_fwd(mem_, d, P(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, k.cv, d, (long long)B * K, d, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(cross_attn_fwd_launch(k.cq, k.ck, k.cv, k.cao, k.cP, B, T, K, d, NH, p, last_.seed, site + 2, st));
+        RC(lin_fwd(k.cao, d, P(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, k.x2, d, BT, d, d, 0, k.x1, d, p, site + 3, st));
+        // feed forward
+        RC(layernorm_fwd_launch(k.x2, P(pre + "ffn_layer_norm.weight"), P(pre + "ffn_layer_norm.bias"), k.ln3, k.ln3_mean, k.ln3_rstd, BT, d, st));
+        RC(lin_fwd(k.ln3, d, P(pre + "ffn.0.weight"), P(pre + "ffn.0.bias"), k.f1, 4 * d, BT, 4 * d, d, 1, nullptr, 0, 0.f, 0, st));
+        RC(lin_fwd(k.f1, 4 * d, P(pre + "ffn.2.weight"), P(pre + "ffn.2.bias"), k.x3, d, BT, d, 4 * d, 0, k.x2, d, p, site + 4, st));
+        xin = k.x3;
+    }
+    RC(layernorm_fwd_launch(xin, P("_tfdec.layer_norm.weight"), P("_tfdec.layer_norm.bias"), lnf_, lnf_mean_, lnf_rstd_, BT, d, st));
+    RC(lin_fwd(lnf_, d, P("_out.weight"), nullptr, pred_, V, BT, V, d, 0, nullptr, 0, 0.f, 0, st));
+    RC(ce_launch(pred_, tokens_, metrics_ + 1, BT, V, B, 1, scratch_, scratch_floats_, st));   // pred_ <- d loss / d pred
+    return 0;
+}
+
+int SlateModel::forward(const StepInputs& in, hipStream_t st) {
+    OCRL_REQUIRE(p_ && ws_, "forward: model not bound");
+    OCRL_REQUIRE(in.B >= 1 && in.B <= Bmax, "forward: batch %d outside [1,%d]", in.B, Bmax);
+    OCRL_REQUIRE(in.obs && in.tau > 0.f, "forward: bad inputs");
+    last_ = in;
+    pdrop_ = in.train ? cfg.dropout : 0.f;
+    RC(pack_weights(st));
+    RC(fwd_dvae(in, st));
+    RC(fwd_encoder(in, st));
+    RC(fwd_decoder(st));
+    RC(copy_launch(metrics_ + 0, metrics_ + 2, 1, st));
+    RC(axpy_launch(metrics_ + 1, metrics_ + 2, 1, 1.f, st));      // loss = dvae_mse + cross_entropy
+    have_fwd_ = true;
+    return 0;
+}
+
+int SlateModel::encode(const StepInputs& in, hipStream_t st) {
+    OCRL_REQUIRE(p_ && ws_, "encode: model not bound");
+    OCRL_REQUIRE(in.B >= 1 && in.B <= Bmax && in.obs, "encode: bad inputs");
+    last_ = in;
+    pdrop_ = 0.f;
+    RC(pack_weights(st));
+    RC(fwd_encoder(in, st));
+    have_fwd_ = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+int SlateModel::bwd_decoder(hipStream_t st) {
+    const int B = last_.B;
+    const long long BT = (long long)B * T, BK = (long long)B * K;
+    const float p = pdrop_;
+    const float scale = 1.0f / sqrtf((float)DH);
+    // output head: pred_ already holds d loss / d pred
+    RC(lin_bwd_w(pred_, V, lnf_, d, G("_out.weight"), nullptr, BT, V, d, 1.f, st));
+    RC(lin_bwd_x(pred_, V, P("_out.weight"), gt1_, d, BT, V, d, nullptr, 0, nullptr, 0, st));
+    const float* xlast = blk_[NB - 1].x3;
+    RC(layernorm_bwd_launch(gt1_, xlast, lnf_mean_, lnf_rstd_, P("_tfdec.layer_norm.weight"), gx_, G("_tfdec.layer_norm.weight"), BT, d, 0, 0,
+                            scratch_, scratch_floats_, st));
+    RC(fill_launch(gmem_, BK * d, 0.f, st));
+    for (int b = NB - 1; b >= 0; --b) {
+        Blk& k = blk_[b];
+        const std::string pre = fmt("_tfdec.blocks.%d.", b);
+        const unsigned site = SITE_BLK_BASE + 8 * b;
+        const float* xin = (b == 0) ? emb_ : blk_[b - 1].x3;
+        // ---- feed forward:  x3 = x2 + drop(W2 relu(W1 ln3 + b1) + b2)
+        const float* gb = gx_;
+        if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 4, st)); gb = gbr_; }
+        RC(lin_bwd_w(gb, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d, 1.f, st));
+        RC(lin_bwd_x(gb, d, P(pre + "ffn.2.weight"), gf1_, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st));
+        RC(lin_bwd_w(gf1_, 4 * d, k.ln3, d, G(pre + "ffn.0.weight"), G(pre + "ffn.0.bias"), BT, 4 * d, d, 1.f, st));
+        RC(lin_bwd_x(gf1_, 4 * d, P(pre + "ffn.0.weight"), gt1_, d, BT, 4 * d, d, nullptr, 0, nullptr, 0, st));
+        RC(layernorm_bwd_launch(gt1_, k.x2, k.ln3_mean, k.ln3_rstd, P(pre + "ffn_layer_norm.weight"), gx_, G(pre + "ffn_layer_norm.weight"), BT, d, 1, 0,
+                                scratch_, scratch_floats_, st));
+        // ---- cross attention
+        gb = gx_;
+        if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 3, st)); gb = gbr_; }
+        RC(lin_bwd_w(gb, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gb, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d cao
+        RC(fill_launch(gck_, BK * d, 0.f, st));
+        RC(fill_launch(gcv_, BK * d, 0.f, st));
+        RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, gt2_, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, st));   // gt2 = d cq
+        RC(lin_bwd_w(gt2_, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gt2_, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
+        RC(lin_bwd_w(gck_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, BK, d, d, 1.f, st));
+        RC(lin_bwd_w(gcv_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, BK, d, d, 1.f, st));
+        RC(lin_bwd_x(gck_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, st));
+        RC(lin_bwd_x(gcv_, d, P(pre + "encoder_decoder_attn.proj_v.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, st));
+        RC(layernorm_bwd_launch(gt1_, k.x1, k.ln2_mean, k.ln2_rstd, P(pre + "encoder_decoder_attn_layer_norm.weight"), gx_,
+                                G(pre + "encoder_decoder_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
+        // ---- causal self attention
+        gb = gx_;
+        if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 1, st)); gb = gbr_; }
+        RC(lin_bwd_w(gb, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gb, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt1 = d ao
+        const float* Pd = k.P;
+        if (p > 0.f) { RC(dropout_apply_launch(k.P, Pd_, (long long)B * NH * T * T, p, last_.seed, site + 0, st)); Pd = Pd_; }
+        GemmArgs a;
+        // dPd = d ao_h v_h^T
+        a = GemmArgs();
+        a.A = gt1_; a.B = k.v; a.C = dP_; a.M = T; a.N = T; a.K = DH; a.lda = d; a.ldb = d; a.ldc = T; a.akc = 1; a.bkc = 1;
+        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)T * d; a.sAi = DH; a.sB = (long long)T * d; a.sBi = DH;
+        a.sC = (long long)NH * T * T; a.sCi = (long long)T * T;
+        RC(gemm_launch(a, st));
+        // dv_h = Pd^T d ao_h
+        a = GemmArgs();
+        a.A = Pd; a.B = gt1_; a.C = gt3_; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 0; a.bkc = 0;
+        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
+        a.sC = (long long)T * d; a.sCi = DH;
+        RC(gemm_launch(a, st));                                                                  // gt3 = dv
+        RC(softmax_causal_bwd_launch(k.P, dP_, (long long)B * NH, T, p, last_.seed, site + 0, st));   // dP_ <- dS
+        RC(lin_bwd_w(gt3_, d, k.ln1, d, G(pre + "self_attn.proj_v.weight"), nullptr, BT, d, d, 1.f, st));
+        // d ln1 accumulates the three projections; start with v
+        RC(lin_bwd_x(gt3_, d, P(pre + "self_attn.proj_v.weight"), gt2_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt2 = d ln1 (v part)
+        // dq_h = scale dS k_h
+        a = GemmArgs();
+        a.A = dP_; a.B = k.k; a.C = gt1_; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 1; a.bkc = 0;
+        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
+        a.sC = (long long)T * d; a.sCi = DH; a.alpha = scale;
+        RC(gemm_launch(a, st));                                                                  // gt1 = dq
+        // dk_h = scale dS^T q_h
+        a = GemmArgs();
+        a.A = dP_; a.B = k.q; a.C = gt3_; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 0; a.bkc = 0;
+        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
+        a.sC = (long long)T * d; a.sCi = DH; a.alpha = scale;
+        RC(gemm_launch(a, st));                                                                  // gt3 = dk
+        RC(lin_bwd_w(gt1_, d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_w(gt3_, d, k.ln1, d, G(pre + "self_attn.proj_k.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gt1_, d, P(pre + "self_attn.proj_q.weight"), gt2_, d, BT, d, d, nullptr, 0, gt2_, d, st));
+        RC(lin_bwd_x(gt3_, d, P(pre + "self_attn.proj_k.weight"), gt2_, d, BT, d, d, nullptr, 0, gt2_, d, st));      // gt2 = d ln1
+        if (b == 0) {
+            // ln1 is both the attention input and the residual stream: d ln1_total = gx + gt2, then LN backward to emb
+            RC(axpy_launch(gx_, gt2_, BT * d, 1.f, st));
+            RC(layernorm_bwd_launch(gt2_, xin, k.ln1_mean, k.ln1_rstd, P(pre + "self_attn_layer_norm.weight"), gx_,
+                                    G(pre + "self_attn_layer_norm.weight"), BT, d, 0, 0, scratch_, scratch_floats_, st));
+        } else {
+            RC(layernorm_bwd_launch(gt2_, xin, k.ln1_mean, k.ln1_rstd, P(pre + "self_attn_layer_norm.weight"), gx_,
+                                    G(pre + "self_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
+        }
+    }
+    // ---- embedding: gx_ = d emb (after dropout);  dictionary (atomics), pe / bos (sum over the batch)
+    RC(fill_launch(G("_dict.dictionary.weight"), (long long)V * d, 0.f, st));
+    RC(embed_bwd_launch(gx_, tokens_, G("_dict.dictionary.weight"), B, T, d, p, last_.seed, st));
+    RC(fill_launch(G("_z_pos.pe"), (long long)(T + 1) * d, 0.f, st));
+    RC(colsum_launch(gx_, (long long)T * d, G("_z_pos.pe"), B, T * d, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(copy_launch(G("_z_pos.pe"), G("_bos_token._bos_token"), d, st));
+    // ---- slot projection
+    RC(lin_bwd_w(gmem_, d, slots_, D, G("_slotproj.weight"), nullptr, BK, d, D, 1.f, st));
+    RC(lin_bwd_x(gmem_, d, P("_slotproj.weight"), gslots_, D, BK, d, D, nullptr, 0, nullptr, 0, st));
+    return 0;
+}
+
+int SlateModel::bwd_encoder(hipStream_t st) {
+    const int B = last_.B;
+    const long long BN = (long long)B * N, R = (long long)B * I * K;
+    const SaSave so = sa_save_layout(C, D, H);
+    const SaGrad go = sa_grad_layout(C, D, H);
+    const std::string sa = "_slotattn.slot_attention.";
+    SlotAttnArgs a;
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
+    a.x = x_; a.wts = sa_wts_; a.save = sa_save_; a.dslots = gslots_; a.dx = gA_; a.dslots0 = gslots0_; a.grows = sa_grows_; a.g_small = sa_small_;
+    RC(slot_attn_launch(a, 1, st));
+    // weight gradients: contract the emitted gradient rows with the saved activations over (image, iteration, slot)
+    RC(lin_bwd_w(sa_grows_ + go.out, go.ld, sa_save_ + so.hid, so.ld, G(sa + "mlp.2.weight"), G(sa + "mlp.2.bias"), R, D, H, 1.f, st));
+    RC(lin_bwd_w(sa_grows_ + go.hid, go.ld, sa_save_ + so.m, so.ld, G(sa + "mlp.0.weight"), G(sa + "mlp.0.bias"), R, H, D, 1.f, st));
+    RC(lin_bwd_w(sa_grows_ + go.gi, go.ld, sa_save_ + so.u, so.ld, G(sa + "gru.weight_ih"), G(sa + "gru.bias_ih"), R, 3 * D, D, 1.f, st));
+    RC(lin_bwd_w(sa_grows_ + go.gh, go.ld, sa_save_ + so.sprev, so.ld, G(sa + "gru.weight_hh"), G(sa + "gru.bias_hh"), R, 3 * D, D, 1.f, st));
+    RC(lin_bwd_w(sa_grows_ + go.u, go.ld, sa_save_ + so.up, so.ld, G(sa + "project_v.weight"), nullptr, R, D, C, 1.f, st));
+    RC(lin_bwd_w(sa_grows_ + go.q, go.ld, sa_save_ + so.sn, so.ld, G(sa + "project_q.weight"), nullptr, R, D, D, 1.f, st));
+    RC(lin_bwd_w(sa_save_ + so.q, so.ld, sa_grows_ + go.qp, go.ld, G(sa + "project_k.weight"), nullptr, R, D, C, a.scale, st));
+    const int SM = 4 * D + 2 * C;
+    RC(colsum_launch(sa_small_ + 0, SM, G(sa + "norm_slots.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(colsum_launch(sa_small_ + 2 * D, SM, G(sa + "norm_mlp.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(colsum_launch(sa_small_ + 4 * D, SM, G(sa + "norm_inputs.weight"), B, 2 * C, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(slot_init_bwd_launch(gslots0_, P("_slotattn.slot_log_sigma"), last_.noise_slots, G("_slotattn.slot_mu"), G("_slotattn.slot_log_sigma"),
+                            B * K, D, last_.seed, st));
+    // ---- input MLP: x = W2 relu(W0 LN(e4) + b0) + b2 ; gA = dx
+    RC(lin_bwd_w(gA_, C, h1_, C, G("_slotattn.mlp.2.weight"), G("_slotattn.mlp.2.bias"), BN, C, C, 1.f, st));
+    RC(lin_bwd_x(gA_, C, P("_slotattn.mlp.2.weight"), gB_, C, BN, C, C, h1_, C, nullptr, 0, st));              // gB = d h1 (pre-relu)
+    RC(lin_bwd_w(gB_, C, ln0_, C, G("_slotattn.mlp.0.weight"), G("_slotattn.mlp.0.bias"), BN, C, C, 1.f, st));
+    RC(lin_bwd_x(gB_, C, P("_slotattn.mlp.0.weight"), gA_, C, BN, C, C, nullptr, 0, nullptr, 0, st));           // gA = d ln0
+    RC(layernorm_bwd_launch(gA_, e4_, ln0_mean_, ln0_rstd_, P("_slotattn.layer_norm.weight"), gB_, G("_slotattn.layer_norm.weight"), BN, C, 0, 0,
+                            scratch_, scratch_floats_, st));                                                      // gB = d e4
+    // ---- positional embedding (added to every image): d map = sum over images
+    RC(colsum_launch(gB_, (long long)N * C, gmap_, B, N * C, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(lin_bwd_w(gmap_, C, gridT_, 4, G("_enc_pos.channels_map.weight"), G("_enc_pos.channels_map.bias"), N, C, 4, 1.f, st));
+    // ---- CNN encoder, last layer first
+    RC(conv_layer_wgrad(e3_, gB_, G("_enc._encoder.3.weight"), G("_enc._encoder.3.bias"), B, S, S, 5, 64, 64, st));
+    RC(conv_layer_fwd(gB_, cw_bwd_[3], nullptr, gA_, B, S, S, 5, 64, 0, nullptr, e3_, st));                       // gA = d e3 (pre-relu)
+    RC(conv_layer_wgrad(e2_, gA_, G("_enc._encoder.2.m.weight"), G("_enc._encoder.2.m.bias"), B, S, S, 5, 64, 64, st));
+    RC(conv_layer_fwd(gA_, cw_bwd_[2], nullptr, gB_, B, S, S, 5, 64, 0, nullptr, e2_, st));
+    RC(conv_layer_wgrad(e1_, gB_, G("_enc._encoder.1.m.weight"), G("_enc._encoder.1.m.bias"), B, S, S, 5, 64, 64, st));
+    RC(conv_layer_fwd(gB_, cw_bwd_[1], nullptr, gA_, B, S, S, 5, 64, 0, nullptr, e1_, st));
+    RC(conv_layer_wgrad(obs8_, gA_, G("_enc._encoder.0.m.weight"), G("_enc._encoder.0.m.bias"), B, S, S, 5, 8, cfg.obs_channels, st));
+    return 0;
+}
+
+int SlateModel::bwd_dvae(hipStream_t st) {
+    const int B = last_.B;
+    const long long BT = (long long)B * T, BN = (long long)B * N;
+    const int ch = cfg.obs_channels;
+    // ---- output conv 64 -> 3 (padded to 4 columns): dW through a [4,64] scratch
+    float* w4 = scratch_ + scratch_floats_ - 1024;      // tail of the scratch region, not touched by split-k / colsum
+    {
+        GemmArgs a;
+        a.A = drecon_; a.B = ps2_; a.C = w4; a.M = 4; a.N = 64; a.K = (int)BN; a.lda = 4; a.ldb = 64; a.ldc = 64; a.akc = 0; a.bkc = 0;
+        long long splits = BN / 512; if (splits > 512) splits = 512; if (splits < 1) splits = 1;
+        if (splits > 1) {
+            a.splitk = (int)splits; a.C = scratch_; a.sCsplit = 256;
+            RC(gemm_launch(a, st));
+            RC(splitk_reduce_launch(scratch_, w4, 256, (int)splits, 256, 0, st));
+        } else RC(gemm_launch(a, st));
+        RC(copy_launch(w4, G("_dvae._decoder.11.weight"), ch * 64, st));
+        RC(colsum_launch(drecon_, 4, G("_dvae._decoder.11.bias"), BN, ch, 0, 1.f, scratch_, scratch_floats_ - 1024, st));
+    }
+    RC(lin_bwd_x(drecon_, 4, w11p_, gdA_, 64, BN, 4, 64, nullptr, 0, nullptr, 0, st));                            // gdA = d ps2
+    RC(pixel_shuffle_launch(gdA_, gdB_, B, 2 * E, 2 * E, 64, 0, dd9_, st));                                        // gdB = d dd9 (pre-relu) [4BT,256]
+    RC(lin_bwd_w(gdB_, 256, dd8_, 64, G("_dvae._decoder.9.m.weight"), G("_dvae._decoder.9.m.bias"), 4 * BT, 256, 64, 1.f, st));
+    RC(lin_bwd_x(gdB_, 256, P("_dvae._decoder.9.m.weight"), gdA_, 64, 4 * BT, 256, 64, dd8_, 64, nullptr, 0, st));
+    RC(lin_bwd_w(gdA_, 64, dd7_, 64, G("_dvae._decoder.8.m.weight"), G("_dvae._decoder.8.m.bias"), 4 * BT, 64, 64, 1.f, st));
+    RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.8.m.weight"), gdB_, 64, 4 * BT, 64, 64, dd7_, 64, nullptr, 0, st));
+    RC(lin_bwd_w(gdB_, 64, dd6_, 64, G("_dvae._decoder.7.m.weight"), G("_dvae._decoder.7.m.bias"), 4 * BT, 64, 64, 1.f, st));
+    RC(lin_bwd_x(gdB_, 64, P("_dvae._decoder.7.m.weight"), gdA_, 64, 4 * BT, 64, 64, dd6_, 64, nullptr, 0, st));   // gdA = d dd6 (pre-relu)
+    RC(conv_layer_wgrad(ps1_, gdA_, G("_dvae._decoder.6.m.weight"), G("_dvae._decoder.6.m.bias"), B, 2 * E, 2 * E, 3, 64, 64, st));
+    RC(conv_layer_fwd(gdA_, dw_bwd_[1], nullptr, gdB_, B, 2 * E, 2 * E, 3, 64, 0, nullptr, ps1_, st));             // gdB = d ps1 (relu mask of dd4)
+    RC(pixel_shuffle_launch(gdB_, gdA_, B, E, E, 64, 0, nullptr, st));                                             // gdA = d dd4 (pre-relu) [BT,256]
+    RC(lin_bwd_w(gdA_, 256, dd3_, 64, G("_dvae._decoder.4.m.weight"), G("_dvae._decoder.4.m.bias"), BT, 256, 64, 1.f, st));
+    RC(lin_bwd_x(gdA_, 256, P("_dvae._decoder.4.m.weight"), gdB_, 64, BT, 256, 64, dd3_, 64, nullptr, 0, st));
+    RC(lin_bwd_w(gdB_, 64, dd2_, 64, G("_dvae._decoder.3.m.weight"), G("_dvae._decoder.3.m.bias"), BT, 64, 64, 1.f, st));
+    RC(lin_bwd_x(gdB_, 64, P("_dvae._decoder.3.m.weight"), gdA_, 64, BT, 64, 64, dd2_, 64, nullptr, 0, st));
+    RC(lin_bwd_w(gdA_, 64, dd1_, 64, G("_dvae._decoder.2.m.weight"), G("_dvae._decoder.2.m.bias"), BT, 64, 64, 1.f, st));
+    RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.2.m.weight"), gdB_, 64, BT, 64, 64, dd1_, 64, nullptr, 0, st));       // gdB = d dd1 (pre-relu)
+    RC(conv_layer_wgrad(dd0_, gdB_, G("_dvae._decoder.1.m.weight"), G("_dvae._decoder.1.m.bias"), B, E, E, 3, 64, 64, st));
+    RC(conv_layer_fwd(gdB_, dw_bwd_[0], nullptr, gdA_, B, E, E, 3, 64, 0, nullptr, dd0_, st));                     // gdA = d dd0 (pre-relu)
+    RC(lin_bwd_w(gdA_, 64, z_, V, G("_dvae._decoder.0.m.weight"), G("_dvae._decoder.0.m.bias"), BT, 64, V, 1.f, st));
+    float* dz = pred_;      // the [BT,V] buffer is free again (decoder backward ran first)
+    RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.0.m.weight"), dz, V, BT, 64, V, nullptr, 0, nullptr, 0, st));
+    // ---- Gumbel softmax + log_softmax backward (row sums of the soft-max gradient vanish, so d raw = d logp)
+    RC(softmax_bwd_rows_launch(z_, dz, BT, V, 1.0f / last_.tau, st));
+    // ---- encoder
+    RC(lin_bwd_w(dz, V, de_[6], 64, G("_dvae._encoder.7.weight"), G("_dvae._encoder.7.bias"), BT, V, 64, 1.f, st));
+    RC(lin_bwd_x(dz, V, P("_dvae._encoder.7.weight"), gdA_, 64, BT, V, 64, de_[6], 64, nullptr, 0, st));
+    float* cur = gdA_;
+    float* oth = gdB_;
+    for (int i = 6; i >= 1; --i) {
+        RC(lin_bwd_w(cur, 64, de_[i - 1], 64, G(fmt("_dvae._encoder.%d.m.weight", i)), G(fmt("_dvae._encoder.%d.m.bias", i)), BT, 64, 64, 1.f, st));
+        RC(lin_bwd_x(cur, 64, P(fmt("_dvae._encoder.%d.m.weight", i)), oth, 64, BT, 64, 64, de_[i - 1], 64, nullptr, 0, st));
+        float* t = cur; cur = oth; oth = t;
+    }
+    RC(lin_bwd_w(cur, 64, patches_, 16 * ch, G("_dvae._encoder.0.m.weight"), G("_dvae._encoder.0.m.bias"), BT, 64, 16 * ch, 1.f, st));
+    return 0;
+}
+
+int SlateModel::backward(hipStream_t st) {
+    OCRL_REQUIRE(have_fwd_, "backward: call forward first");
+    OCRL_REQUIRE(g_, "backward: no gradient buffer bound");
+    RC(bwd_decoder(st));
+    RC(bwd_encoder(st));
+    RC(bwd_dvae(st));
+    have_fwd_ = false;
+    return 0;
+}
+
+int SlateModel::grad_norm(hipStream_t st) {
+    return absmax_launch(g_, flat_size_, metrics_ + 3, scratch_, scratch_floats_, st);
+}
+
+int SlateModel::clip_adam(const float lr[3], float clip, int step, float gscale, hipStream_t st) {
+    OCRL_REQUIRE(m_ && v_, "clip_adam: optimiser state not bound");
+    RC(grad_norm(st));
+    for (int g = 0; g < 3; ++g) {
+        const long long b0 = group_begin_[g], n = group_begin_[g + 1] - b0;
+        RC(clip_adam_launch(p_ + b0, g_ + b0, m_ + b0, v_ + b0, n, metrics_ + 3, clip, lr[g], 0.9f, 0.999f, 1e-8f, step, gscale, st));
+    }
+    return 0;
+}

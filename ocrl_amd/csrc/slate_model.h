@@ -1,0 +1,124 @@
+// SLATE training-step orchestration over the HIP kernels (host code).  One object per process
+// per GPU; not thread-safe; every launch goes to the caller's stream.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+struct SlateConfig {
+    int obs_size = 64, obs_channels = 3, vocab = 4096, d_model = 192, cnn_hidden = 64;
+    int num_slots = 5, num_iters = 3, slot_size = 192, mlp_hidden = 192;
+    int num_blocks = 4, num_heads = 4;
+    float dropout = 0.1f;
+    int max_batch = 1;
+};
+
+struct ParamInfo {
+    std::string name;
+    int shape[4] = {1, 1, 1, 1};
+    int ndim = 1;
+    long long numel = 0;
+    long long offset = 0;   // element offset into the flat parameter buffer (16-byte aligned)
+    int group = 0;          // optimiser group: 0 dvae, 1 slot-attention side, 2 transformer decoder
+};
+
+struct StepInputs {
+    const float* obs = nullptr;        // [B,3,S,S] NCHW fp32 in [0,1]
+    int B = 0;
+    float tau = 1.f;
+    int train = 1;                     // dropout on/off
+    unsigned long long seed = 0;       // device RNG stream for this step (noise + dropout)
+    const float* noise_z = nullptr;    // optional injected Exp(1) draws [B,T,V] (both or none)
+    const float* noise_zh = nullptr;
+    const float* noise_slots = nullptr;  // optional injected N(0,1) [B,K,D]
+};
+
+class SlateModel {
+public:
+    explicit SlateModel(const SlateConfig& c);
+    const std::vector<ParamInfo>& params() const { return params_; }
+    long long flat_size() const { return flat_size_; }
+    long long group_begin(int g) const { return group_begin_[g]; }   // group g = [begin(g), begin(g+1))
+    size_t workspace_bytes() const { return ws_bytes_; }
+    int bind(float* p, float* g, float* m, float* v, void* ws, size_t ws_bytes);
+    int forward(const StepInputs& in, hipStream_t st);          // loss terms -> metrics()
+    int backward(hipStream_t st);                               // fills the flat gradient buffer
+    int encode(const StepInputs& in, hipStream_t st);           // slots + attention only (inference path)
+    int clip_adam(const float lr[3], float clip, int step, float gscale, hipStream_t st);
+    int grad_norm(hipStream_t st);                              // metrics()[3] = max |g|
+    float* metrics() const { return metrics_; }                 // device float[8]: dvae_mse, ce, loss, grad absmax
+    int tensor(const char* name, float** ptr, long long* count) const;
+    int dropout_mask(unsigned site, long long n, float* out, hipStream_t st) const;
+    const SlateConfig cfg;
+
+private:
+    float* P(const std::string& n) const;
+    float* G(const std::string& n) const;
+    float* carve(const char* name, size_t n);
+    void layout_workspace(bool commit);
+    int lin_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, long long M, int N, int K, int relu,
+                const float* resid, int ldr, float drop_p, unsigned site, hipStream_t st);
+    int lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx, int ldx, long long M, int N_out, int K_in, const float* mask,
+                  int ldmask, const float* resid, int ldr, hipStream_t st);
+    int lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in,
+                  float alpha, hipStream_t st);
+    int conv_layer_fwd(const float* x, const float* pack, const float* bias, float* y, int Bn, int Hh, int Ww, int KS, int CIN, int relu,
+                       const float* posmap, const float* mask, hipStream_t st);
+    int conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN, int cin_real,
+                         hipStream_t st);
+    int pack_weights(hipStream_t st);
+    int fwd_encoder(const StepInputs& in, hipStream_t st);
+    int fwd_dvae(const StepInputs& in, hipStream_t st);
+    int fwd_decoder(hipStream_t st);
+    int bwd_decoder(hipStream_t st);
+    int bwd_encoder(hipStream_t st);
+    int bwd_dvae(hipStream_t st);
+
+    std::vector<ParamInfo> params_;
+    std::map<std::string, int> index_;
+    long long flat_size_ = 0;
+    long long group_begin_[4] = {0, 0, 0, 0};
+    float *p_ = nullptr, *g_ = nullptr, *m_ = nullptr, *v_ = nullptr;
+    char* ws_ = nullptr;
+    size_t ws_bytes_ = 0, ws_off_ = 0;
+    bool ws_commit_ = false;
+    std::map<std::string, std::pair<float*, size_t>> named_;
+    float* metrics_ = nullptr;
+
+    // dims
+    int S, E, T, N, V, d, C, K, I, D, H, NB, NH, DH, Bmax;
+    // last step
+    StepInputs last_;
+    float pdrop_ = 0.f;
+    bool have_fwd_ = false;
+
+    // ---- workspace tensors
+    float *scratch_ = nullptr;            // transient: split-k slabs, column-sum partials, wgrad slabs
+    size_t scratch_floats_ = 0;
+    float *obs8_, *patches_, *de_[7], *zraw_, *z_;
+    int* tokens_;
+    float *dd0_, *dd1_, *dd2_, *dd3_, *dd4_, *ps1_, *dd6_, *dd7_, *dd8_, *dd9_, *ps2_, *recon_, *drecon_;
+    float *e1_, *e2_, *e3_, *e4_, *posmap_, *gridT_, *ln0_, *ln0_mean_, *ln0_rstd_, *h1_, *x_;
+    float *slots0_, *slot_noise_, *slots_, *attn_, *sa_save_, *sa_wts_, *sa_grows_, *sa_small_;
+    PackEntry* sa_pack_dev_ = nullptr;
+    int sa_pack_n_ = 0, sa_pack_max_ = 0;
+    float *cw_fwd_[4], *cw_bwd_[4];       // CNN encoder conv packs
+    float *dw_fwd_[2], *dw_bwd_[2];       // dVAE decoder 3x3 conv packs
+    float *w11p_;                         // [4,64] padded copy of the dVAE output conv
+    float *mem_, *emb_;
+    struct Blk {
+        float *ln1, *ln1_mean, *ln1_rstd, *q, *k, *v, *P, *ao, *x1;
+        float *ln2, *ln2_mean, *ln2_rstd, *cq, *ck, *cv, *cP, *cao, *x2;
+        float *ln3, *ln3_mean, *ln3_rstd, *f1, *x3;
+    };
+    std::vector<Blk> blk_;
+    float *Pd_, *dP_;                     // shared [B*h,T,T] temporaries
+    float *lnf_, *lnf_mean_, *lnf_rstd_, *pred_;
+    // gradient temporaries
+    float *gx_, *gbr_, *gt1_, *gt2_, *gt3_, *gf1_, *gmem_, *gck_, *gcv_, *gslots_, *gslots0_;
+    float *gA_, *gB_;                     // [B*N,64] (CNN encoder / slot-attention input gradients)
+    float *gdA_, *gdB_;                   // dVAE decoder gradient ping-pong (up to [B*4T,256])
+    float *gmap_;
+};

@@ -1,0 +1,200 @@
+"""Whole-path parity: the HIP SLATE step (through the C ABI) against the CPU oracle on identical weights,
+inputs and injected noise.  Stated tolerances (fp32, different summation order):
+  loss terms 1e-5 rel; activations 1e-4 rel (max-norm); gradients 1e-3 rel to each tensor's max
+  (floored at 1e-5 x the largest gradient); parameters after Adam steps 1e-4 rel."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import dims_from_cfg, load_params, log, relerr
+from oracle import slate_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2)
+MID = dict(obs_size=32, vocab_size=512, num_slots=5, num_iterations=2, num_dec_blocks=2)
+
+
+def make_engine(cfg, B):
+    from ocrl_amd.engine import SlateEngine
+    return SlateEngine(dims_from_cfg(cfg), max_batch=B)
+
+
+def dev_noise(cfg, noise):
+    B = noise["z"].shape[0]
+    T = (cfg.obs_size // 4) ** 2
+    f = lambda t: t.permute(0, 2, 3, 1).reshape(B, T, cfg.vocab_size).contiguous().cuda()
+    return dict(z=f(noise["z"]), z_hard=f(noise["z_hard"]), slots=noise["slots"].contiguous().cuda())
+
+
+def site_masks(eng, cfg, B):
+    """dropout keep-masks of the last forward, keyed for the oracle"""
+    T = (cfg.obs_size // 4) ** 2
+    d, h, K = cfg.d_model, cfg.num_dec_heads, cfg.num_slots
+    M = {"z_pos": eng.dropout_mask(1, (B, T + 1, d)).cpu()}
+    for b in range(cfg.num_dec_blocks):
+        s = 16 + 8 * b
+        M[f"blk{b}.self.attn"] = eng.dropout_mask(s + 0, (B, h, T, T)).cpu()
+        M[f"blk{b}.self.out"] = eng.dropout_mask(s + 1, (B, T, d)).cpu()
+        M[f"blk{b}.cross.attn"] = eng.dropout_mask(s + 2, (B, h, T, K)).cpu()
+        M[f"blk{b}.cross.out"] = eng.dropout_mask(s + 3, (B, T, d)).cpu()
+        M[f"blk{b}.ffn"] = eng.dropout_mask(s + 4, (B, T, d)).cpu()
+    return M
+
+
+def compare_forward(tag, eng, cfg, res, B):
+    S, E = cfg.obs_size, cfg.obs_size // 4
+    T, N, V, K, D, d = E * E, S * S, cfg.vocab_size, cfg.num_slots, cfg.slot_size, cfg.d_model
+    errs = {}
+    zl = torch.log_softmax(eng.tensor("zraw", (B, T, V)).cpu(), -1)
+    errs["z_logits"] = relerr(zl, res["z_logits"].permute(0, 2, 3, 1).reshape(B, T, V))
+    errs["z"] = relerr(eng.tensor("z", (B, T, V)), res["z"].permute(0, 2, 3, 1).reshape(B, T, V))
+    tok = eng.tensor("tokens", (B, T), torch.int32).cpu().long()
+    errs["tokens_mismatch"] = float((tok != res["tokens"]).sum().item())
+    errs["recon"] = relerr(eng.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2), res["recon"])
+    errs["feats"] = relerr(eng.tensor("feats", (B, N, 64)), res["feats"])
+    errs["slots"] = relerr(eng.tensor("slots", (B, K, D)), res["slots"])
+    errs["attn"] = relerr(eng.tensor("attn", (B, N, K)), res["attn"])
+    errs["dec_out"] = relerr(eng.tensor("dec_out", (B, T, d)), res["dec_out"])
+    m = eng.metrics.cpu()
+    errs["dvae_mse"] = abs(m[0].item() - res["dvae_mse"].item()) / abs(res["dvae_mse"].item())
+    errs["cross_entropy"] = abs(m[1].item() - res["cross_entropy"].item()) / abs(res["cross_entropy"].item())
+    errs["loss"] = abs(m[2].item() - res["loss"].item()) / abs(res["loss"].item())
+    log(f"[{tag}] forward: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    return errs
+
+
+def compare_grads(tag, eng, trainer):
+    gmax = max(trainer.P[p.name].grad.abs().max().item() for p in eng.params)
+    worst, rows = 0.0, []
+    for p in eng.params:
+        ref = trainer.P[p.name].grad
+        e = relerr(eng.view(eng.flat_g, p), ref.reshape(p.shape), floor=1e-5 * gmax)
+        rows.append((e, p.name))
+        worst = max(worst, e)
+    rows.sort(reverse=True)
+    log(f"[{tag}] grads: worst {worst:.2e}; top: " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:8]))
+    return worst, rows
+
+
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3)])
+def test_forward_backward_eval(tag, over, B):
+    """dropout off: every stage of the forward, then every parameter gradient"""
+    cfg = O.default_cfg(**over)
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    g = torch.Generator().manual_seed(100)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=g)
+    noise = O.make_noise(cfg, B, 7)
+    step = 10
+    tau, _ = O.schedules(cfg, step)
+    tr = O.OracleTrainer(cfg, P)
+    res = tr.loss_and_grads(obs, noise, step, None)
+    eng.forward(obs.cuda(), tau, train=False, seed=1, noise=dev_noise(cfg, noise))
+    torch.cuda.synchronize()
+    errs = compare_forward(tag, eng, cfg, res, B)
+    assert errs["tokens_mismatch"] == 0
+    for k in ("dvae_mse", "cross_entropy", "loss"):
+        assert errs[k] < 1e-5, (k, errs[k])
+    for k in ("z_logits", "z", "recon", "feats", "slots", "attn", "dec_out"):
+        assert errs[k] < 1e-4, (k, errs[k])
+    eng.backward()
+    torch.cuda.synchronize()
+    worst, rows = compare_grads(tag, eng, tr)
+    assert worst < 1e-3, rows[:5]
+
+
+def test_train_mode_dropout_parity():
+    """train mode: the oracle consumes the exact keep-masks the kernels derived from the seed"""
+    cfg = O.default_cfg(**SMALL)
+    B = 2
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(5))
+    noise = O.make_noise(cfg, B, 11)
+    eng.forward(obs.cuda(), 1.0, train=True, seed=1234, noise=dev_noise(cfg, noise))
+    eng.backward()
+    torch.cuda.synchronize()
+    masks = site_masks(eng, cfg, B)
+    keep = np.mean([m.mean().item() for m in masks.values()])
+    assert abs(keep - 0.9) < 0.01, keep
+    tr = O.OracleTrainer(cfg, P)
+    res = tr.loss_and_grads(obs, noise, 0, masks)
+    m = eng.metrics.cpu()
+    e = abs(m[2].item() - res["loss"].item()) / abs(res["loss"].item())
+    log(f"[dropout] loss rel err {e:.2e} keep-rate {keep:.4f}")
+    assert e < 1e-5
+    worst, rows = compare_grads("dropout", eng, tr)
+    assert worst < 1e-3, rows[:5]
+
+
+def test_update_steps_match_oracle():
+    """three full update() steps (clip + Adam, schedules) against the oracle trainer"""
+    cfg = O.default_cfg(**SMALL)
+    B = 2
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    tr = O.OracleTrainer(cfg, P)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(9))
+    for step in range(3):
+        noise = O.make_noise(cfg, B, 20 + step)
+        tau, lrs = O.schedules(cfg, step)
+        res = tr.update(obs, noise, step, None)
+        eng.forward(obs.cuda(), tau, train=False, seed=step, noise=dev_noise(cfg, noise))
+        eng.backward()
+        eng.clip_adam(lrs, cfg.clip)
+        torch.cuda.synchronize()
+        m = eng.metrics.cpu()
+        el = abs(m[2].item() - res["loss"].item()) / abs(res["loss"].item())
+        en = abs(m[3].item() - float(res["norm"])) / float(res["norm"])
+        worst = max(relerr(eng.view(eng.flat_p, p), tr.P[p.name].reshape(p.shape)) for p in eng.params)
+        log(f"[update] step {step}: loss err {el:.2e} norm err {en:.2e} worst param err {worst:.2e}")
+        assert el < 2e-5 and en < 1e-3 and worst < 1e-4
+
+
+def test_encode_matches_forward_slots():
+    cfg = O.default_cfg(**SMALL)
+    B = 2
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    obs = torch.rand(B, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    noise = O.make_noise(cfg, B, 4)
+    eng.encode(obs.cuda(), seed=0, slot_noise=noise["slots"].cuda())
+    torch.cuda.synchronize()
+    feats = O.cnn_encode(P, obs)
+    slots, attn = O.slot_encoder(P, feats, noise["slots"], cfg)
+    e1, e2 = relerr(eng.tensor("slots", (B, 6, 192)), slots), relerr(eng.tensor("attn", (B, 256, 6)), attn)
+    log(f"[encode] slots {e1:.2e} attn {e2:.2e}")
+    assert e1 < 1e-4 and e2 < 1e-4
+    a = eng.tensor("attn", (B, 256, 6)).sum(-1)
+    assert torch.allclose(a, torch.ones_like(a), atol=1e-5)      # softmax over slots sums to one at every position
+
+
+def test_device_rng_statistics():
+    """no injected noise: Gumbel / slot noise / dropout come from the device RNG; check determinism per seed,
+    sensitivity to the seed, and that z rows are distributions"""
+    cfg = O.default_cfg(**SMALL)
+    B = 2
+    eng = make_engine(cfg, B)
+    load_params(eng, O.formula_params(cfg))
+    obs = torch.rand(B, 3, 16, 16, generator=torch.Generator().manual_seed(3)).cuda()
+    T, V = 16, cfg.vocab_size
+    out = []
+    for seed in (5, 5, 6):
+        eng.forward(obs, 1.0, train=True, seed=seed)
+        torch.cuda.synchronize()
+        out.append((eng.metrics.cpu().clone(), eng.tensor("z", (B, T, V)).cpu().clone(), eng.tensor("slots0", (B, 6, 192)).cpu().clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert not torch.equal(out[0][1], out[2][1])
+    z = out[0][1]
+    assert torch.allclose(z.sum(-1), torch.ones(B, T), atol=1e-4) and (z >= 0).all()
+    s0 = out[0][2]
+    mu = O.formula_params(cfg)["_slotattn.slot_mu"]
+    sig = torch.exp(O.formula_params(cfg)["_slotattn.slot_log_sigma"])
+    eps = (s0 - mu) / sig
+    assert abs(eps.mean().item()) < 0.1 and abs(eps.std().item() - 1.0) < 0.1
+    assert torch.isfinite(out[0][0][:3]).all()
