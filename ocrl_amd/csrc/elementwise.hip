@@ -294,14 +294,15 @@ __global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ pred, const
     __shared__ float red[4];
     const long long row = blockIdx.x;
     float* r = pred + row * V;
+    const int tok = tokens[row];
+    const float rt = r[tok];                 // read before anyone overwrites the row with its gradient
     float mx = -INFINITY;
     for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, r[v]);
     mx = block_max(mx, red);
     float s = 0.f;
     for (int v = threadIdx.x; v < V; v += 256) s += __expf(r[v] - mx);
     s = block_sum(s, red);
-    const int tok = tokens[row];
-    if (threadIdx.x == 0) part[row] = (mx + __logf(s)) - r[tok];
+    if (threadIdx.x == 0) part[row] = (mx + __logf(s)) - rt;
     if (write_grad) {
         const float inv = 1.0f / s;
         for (int v = threadIdx.x; v < V; v += 256) {

@@ -99,10 +99,10 @@ def test_conv_fwd(L, B, S, cin, ks):
     b = torch.randn(64, generator=g)
     ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2))
     cpad = 8 if cin < 8 else 64
-    xd = dev(nhwc(x, cpad))
+    xd, wd, bd = dev(nhwc(x, cpad)), dev(w), dev(b)        # keep references: the launch is asynchronous
     y = torch.empty(B, S, S, 64, device="cuda")
     ws = torch.empty(ks * ks * cpad * 64, device="cuda")
-    L.check(L.lib().ocrl_conv2d_fwd(P(xd), P(dev(w)), P(dev(b)), P(y), B, S, S, cin, cpad, ks, 1, P(ws), None))
+    L.check(L.lib().ocrl_conv2d_fwd(P(xd), P(wd), P(bd), P(y), B, S, S, cin, cpad, ks, 1, P(ws), None))
     torch.cuda.synchronize()
     e = relerr(y.cpu().permute(0, 3, 1, 2), ref)
     log(f"conv fwd B{B} S{S} cin{cin} ks{ks}: {e:.2e}")
@@ -120,7 +120,8 @@ def test_conv_bwd_data(L, B, S, ks):
     ref = x.grad * (act > 0)
     dx = torch.empty(B, S, S, 64, device="cuda")
     ws = torch.empty(2 * ks * ks * 64 * 64, device="cuda")
-    L.check(L.lib().ocrl_conv2d_bwd_data(P(dev(nhwc(dy))), P(dev(w)), P(dev(nhwc(act))), P(dx), B, S, S, ks, P(ws), None))
+    dyd, wd, actd = dev(nhwc(dy)), dev(w), dev(nhwc(act))
+    L.check(L.lib().ocrl_conv2d_bwd_data(P(dyd), P(wd), P(actd), P(dx), B, S, S, ks, P(ws), None))
     torch.cuda.synchronize()
     e = relerr(dx.cpu().permute(0, 3, 1, 2), ref)
     log(f"conv bwd-data B{B} S{S} ks{ks}: {e:.2e}")
@@ -140,7 +141,8 @@ def test_conv_bwd_weight(L, B, S, cin, ks):
     ws = torch.empty(n, device="cuda")
     dw = torch.zeros(64, cin, ks, ks, device="cuda")
     db = torch.zeros(64, device="cuda")
-    L.check(L.lib().ocrl_conv2d_bwd_weight(P(dev(nhwc(x, cpad))), P(dev(nhwc(dy))), P(dw), P(db), B, S, S, cin, cpad, ks, P(ws), n, None))
+    xd, dyd = dev(nhwc(x, cpad)), dev(nhwc(dy))
+    L.check(L.lib().ocrl_conv2d_bwd_weight(P(xd), P(dyd), P(dw), P(db), B, S, S, cin, cpad, ks, P(ws), n, None))
     torch.cuda.synchronize()
     e, eb = relerr(dw.cpu(), w.grad), relerr(db.cpu(), bias.grad)
     log(f"conv wgrad B{B} S{S} cin{cin} ks{ks}: dW {e:.2e} db {eb:.2e}")
