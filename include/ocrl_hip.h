@@ -101,6 +101,12 @@ int ocrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int ocrl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgb,
                        long long R, int F, float* ws, size_t ws_floats, void* stream);
 
+/* ---- optional HIP-event timing of kernel families on the launch stream (bench.py's roofline line).
+ * tag bits: 0 conv5x5/64ch fwd+bwd-data, 1 other convs, 2 conv weight-grad, 3 gemm, 4 slot-attn fwd, 5 slot-attn bwd.
+ * ocrl_prof_collect synchronises the device and returns total milliseconds / launch counts per tag. */
+int ocrl_prof_enable(unsigned tag_mask);
+int ocrl_prof_collect(double* ms, long long* count, int ntags);
+
 #ifdef __cplusplus
 }
 #endif

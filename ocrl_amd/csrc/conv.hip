@@ -236,7 +236,9 @@ static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int grid = cdiv(a.W, TW) * cdiv(a.H, TH) * a.B;
+    const int pi = prof_begin((KS == 5 && CIN == 64) ? PROF_CONV5 : PROF_CONV_OTHER, st);
     hipLaunchKernelGGL((conv_fwd_kernel<KS, CIN, 64>), dim3(grid), dim3(256), smem, st, a);
+    prof_end(pi, st);
     OCRL_CHECK_LAUNCH("conv_fwd_kernel");
     return 0;
 }
@@ -260,7 +262,9 @@ static int conv_wgrad_cfg(const WgradArgs& a, int nchunk, hipStream_t st) {
         OCRL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<KS, CIN, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
+    const int pi = prof_begin(PROF_WGRAD, st);
     hipLaunchKernelGGL((conv_wgrad_kernel<KS, CIN, 64>), dim3(nchunk, KS), dim3(256), smem, st, a);
+    prof_end(pi, st);
     OCRL_CHECK_LAUNCH("conv_wgrad_kernel");
     return 0;
 }

@@ -237,7 +237,9 @@ static int launch_cfg(const GemmArgs& a, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.batch * a.splitk);
+    const int pi = prof_begin(PROF_GEMM, st);
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC>), grid, dim3(256), smem, st, a);
+    prof_end(pi, st);
     OCRL_CHECK_LAUNCH("gemm_kernel");
     return 0;
 }

@@ -3,6 +3,11 @@
 #pragma once
 #include "common.h"
 
+// ------------------------------------------------------------------ prof.cpp
+enum { PROF_CONV5 = 0, PROF_CONV_OTHER = 1, PROF_WGRAD = 2, PROF_GEMM = 3, PROF_SA_FWD = 4, PROF_SA_BWD = 5, PROF_NTAGS = 6 };
+int prof_begin(int tag, hipStream_t st);
+void prof_end(int idx, hipStream_t st);
+
 // ------------------------------------------------------------------ gemm.hip
 struct GemmArgs {
     const float* A = nullptr;

@@ -616,6 +616,7 @@ static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
     const SaWts wo = sa_wts_layout(a.C, a.D, a.H);
     const SaSave so = sa_save_layout(a.C, a.D, a.H);
     const SaGrad go = sa_grad_layout(a.C, a.D, a.H);
+    const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
     if (backward) {
         OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_bwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((slot_attn_bwd_kernel<K>), dim3(a.B), dim3(SA_THREADS), smem, st, a, wo, so, go);
@@ -623,6 +624,7 @@ static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
         OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((slot_attn_fwd_kernel<K>), dim3(a.B), dim3(SA_THREADS), smem, st, a, wo, so);
     }
+    prof_end(pi, st);
     OCRL_CHECK_LAUNCH("slot_attn");
     return 0;
 }

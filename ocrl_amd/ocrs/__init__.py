@@ -1,0 +1,7 @@
+"""Drop-in for the reference's ``ocrs`` package on the SLATE / Slot-Attention path:
+``getattr(ocrs, config.ocr.name)(config.ocr, config.dataset)`` (train_ocr.py:37) and
+``getattr(ocrs, name + "_Module")`` (utils/tools.py:327-331) resolve here."""
+from .base import Base
+from .slate import SLATE, SLATE_Module
+
+__all__ = ["Base", "SLATE", "SLATE_Module"]
