@@ -11,6 +11,7 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
+from ..dist_utils import allreduce_grads_
 from ..engine import SlateEngine
 from .base import Base
 
@@ -414,12 +415,6 @@ class SLATE(Base):
         })
         return (metrics, rep) if with_rep else metrics
 
-    def _dist(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return dist
-        return None
-
     def update(self, obs, masks, step: int) -> dict:
         """ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74: schedules -> loss -> backward ->
         [gradient all-reduce over RCCL when torch.distributed is initialised] -> inf-norm clip -> Adam."""
@@ -432,11 +427,7 @@ class SLATE(Base):
         self._opt.param_groups[2]["lr"] = decay * warm * lr.lr_dec
         metrics = self.get_loss(obs, masks)
         self._module.backward()
-        scale = 1.0
-        dist = self._dist()
-        if dist is not None:
-            dist.all_reduce(self._module.engine.flat_g)          # one flat fp32 buffer, sum; mean folded into the clip kernel
-            scale = 1.0 / dist.get_world_size()
+        scale = allreduce_grads_(self._module.engine.flat_g)     # one flat fp32 buffer; the mean is folded into the clip kernel
         clip = lr.clip if hasattr(lr, "clip") else 0.0
         self._opt.step(clip, scale)
         metrics["norm"] = self._module.engine.metrics[3] * scale
