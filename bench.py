@@ -111,9 +111,9 @@ def main():
         step += 1
     sync()
     dt = time.perf_counter() - t0
-    ms = (ctypes.c_double * 6)()
-    cnt = (ctypes.c_longlong * 6)()
-    _lib.check(L.ocrl_prof_collect(ctypes.byref(ms), ctypes.byref(cnt), 6))
+    ms = (ctypes.c_double * 8)()
+    cnt = (ctypes.c_longlong * 8)()
+    _lib.check(L.ocrl_prof_collect(ctypes.byref(ms), ctypes.byref(cnt), 8))
     L.ocrl_prof_enable(0)
     loss = float(metrics["loss"].item())
     if dist is not None:

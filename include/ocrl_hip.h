@@ -102,7 +102,8 @@ int ocrl_layernorm_bwd(const float* dy, const float* x, const float* mean, const
                        long long R, int F, float* ws, size_t ws_floats, void* stream);
 
 /* ---- optional HIP-event timing of kernel families on the launch stream (bench.py's roofline line).
- * tag bits: 0 conv5x5/64ch fwd+bwd-data, 1 other convs, 2 conv weight-grad, 3 gemm, 4 slot-attn fwd, 5 slot-attn bwd.
+ * tag bits: 0 conv5x5/64ch fwd+bwd-data, 1 other convs, 2 conv weight-grad, 3 gemm, 4 slot-attn fwd, 5 slot-attn bwd,
+ * 6 self-attention fwd, 7 self-attention bwd.
  * ocrl_prof_collect synchronises the device and returns total milliseconds / launch counts per tag. */
 int ocrl_prof_enable(unsigned tag_mask);
 int ocrl_prof_collect(double* ms, long long* count, int ntags);

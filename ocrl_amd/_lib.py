@@ -58,7 +58,7 @@ def lib():
     L.ocrl_layernorm_fwd.argtypes = [p, p, p, p, p, p, c_longlong, c_int, p]
     L.ocrl_layernorm_bwd.argtypes = [p, p, p, p, p, p, p, c_longlong, c_int, p, c_size_t, p]
     L.ocrl_prof_enable.argtypes = [c_uint]
-    L.ocrl_prof_collect.argtypes = [POINTER(ctypes.c_double * 6), POINTER(c_longlong * 6), c_int]
+    L.ocrl_prof_collect.argtypes = [POINTER(ctypes.c_double * 8), POINTER(c_longlong * 8), c_int]
     if L.ocrl_abi_version() != 1:
         raise RuntimeError("libocrl_hip.so ABI version mismatch")
     _lib = L

@@ -1,0 +1,392 @@
+// Causal multi-head self-attention of the SLATE transformer decoder (reference:
+// ocrs/common/transformer.py:23-50), flash-style: scores are never written to HBM.
+// fp32 on v_mfma_f32_16x16x4_f32; softmax statistics online; dropout on the probabilities from the
+// stateless counter RNG (identical decisions in forward and backward, index = ((b*h+head)*T+q)*T+key).
+//
+// Orientation trick (no LDS round trip for P): the forward and the dQ kernel compute S^T = K Q^T, so a lane
+// holds, for its query (lane & 15), the four consecutive keys 4*(lane>>4)+r in accumulator registers r = 0..3 —
+// exactly the B-operand layout of the following  O^T += V^T P^T  (resp. dQ^T += K^T dS^T) MFMA steps.  The
+// dK/dV kernel owns 16 keys per wave (K, V fragments in registers), computes S = Q K^T with queries on rows
+// and feeds P / dS the same way into  dV^T += dO^T P  and  dK^T += Q^T dS.
+//
+// One workgroup = 4 waves = 64 queries (or 64 keys); tiles of 64 keys (queries) stream through LDS.
+#include "common.h"
+#include "kernels.h"
+
+#define FA_BLK 64
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int DH>
+struct FaCfg {
+    static constexpr int NC = DH / 16;       // 16-wide chunks of the head dimension
+    static constexpr int LD = DH + 4;        // LDS row stride (floats)
+};
+
+// cooperative load of a [64 x DH] tile (rows row0.., zero beyond T) of one head into LDS, optionally scaled
+template <int DH>
+__device__ inline void fa_load_tile(float* s, const float* __restrict__ g, long long bt0, int row0, int T, int d, int hoff, float scale) {
+    constexpr int F4 = DH / 4;
+    constexpr int LD = FaCfg<DH>::LD;
+    for (int idx = threadIdx.x; idx < FA_BLK * F4; idx += 256) {
+        const int c4 = idx % F4, r = idx / F4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < T) v = *reinterpret_cast<const float4*>(g + (bt0 + row0 + r) * d + hoff + c4 * 4);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *reinterpret_cast<float4*>(s + r * LD + c4 * 4) = v;
+    }
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------- forward
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD;
+    __shared__ __attribute__((aligned(16))) float Ks[FA_BLK * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[FA_BLK * LD];
+    const int nqb = (p.T + FA_BLK - 1) / FA_BLK;
+    int bid = blockIdx.x;
+    const int qb = nqb - 1 - (bid % nqb); bid /= nqb;       // heaviest (last) query blocks first
+    const int hd = bid % p.h;
+    const long long b = bid / p.h;
+    const int T = p.T, d = p.d, hoff = hd * DH;
+    const long long bt0 = b * T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int q_abs = qb * FA_BLK + wv * 16 + li;            // this lane's query (column of S^T)
+    const float scale = rsqrtf((float)DH);
+    const long long bh = b * p.h + hd;
+
+    float4 qf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q_abs < T) v = *reinterpret_cast<const float4*>(p.q + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g);
+        qf[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    }
+    f32x4_t o[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const uint32_t thr = drop_thresh(p.p);
+    const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
+
+    for (int kt = 0; kt <= qb; ++kt) {
+        __syncthreads();
+        fa_load_tile<DH>(Ks, p.k, bt0, kt * FA_BLK, T, d, hoff, 1.f);
+        fa_load_tile<DH>(Vs, p.v, bt0, kt * FA_BLK, T, d, hoff, 1.f);
+        __syncthreads();
+        f32x4_t s[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(Ks + (16 * st + li) * LD + 16 * c + 4 * g);
+                acc = MFMA16(a.x, qf[c].x, acc);
+                acc = MFMA16(a.y, qf[c].y, acc);
+                acc = MFMA16(a.z, qf[c].z, acc);
+                acc = MFMA16(a.w, qf[c].w, acc);
+            }
+            const int key0 = kt * FA_BLK + 16 * st + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (key0 + r > q_abs || key0 + r >= T) acc[r] = -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            s[st] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (m_new == -INFINITY) ? 0.f : __expf(s[st][r] - m_new);
+                s[st][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] *= alpha;
+        if (p.p > 0.f) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const uint64_t idx = ((uint64_t)bh * T + (uint64_t)(q_abs < T ? q_abs : 0)) * T + (uint64_t)(kt * FA_BLK + 16 * st + 4 * g);
+                const uint2 bits = rng_bits4(p.seed, p.site, idx >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[st][r] = rng_keep(bits, r, thr) ? s[st][r] * dsc : 0.f;
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = Vs[(16 * st + 4 * g + r) * LD + 16 * c + li];
+                    o[c] = MFMA16(a, s[st][r], o[c]);
+                }
+    }
+    if (q_abs < T) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(p.o + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g) = make_float4(o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv);
+        if (g == 0) p.lse[bh * T + q_abs] = m + __logf(l);
+    }
+}
+
+// delta[b,h,q] = sum_dim dO[q,dim] * O[q,dim]   (one thread per (row, head))
+__global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta, long long BT, int T, int d, int h) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BT * h) return;
+    const int hd = i % h;
+    const long long row = i / h;
+    const int dh = d / h;
+    const float* a = dO + row * d + hd * dh;
+    const float* c = O + row * d + hd * dh;
+    float s = 0.f;
+    for (int k = 0; k < dh; k += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(a + k), y = *reinterpret_cast<const float4*>(c + k);
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    const long long b = row / T, q = row % T;
+    delta[(b * h + hd) * T + q] = s;
+}
+
+// ------------------------------------------------------------------------------------------- backward: dK, dV
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
+    constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD;
+    __shared__ __attribute__((aligned(16))) float Qs[FA_BLK * LD];
+    __shared__ __attribute__((aligned(16))) float Gs[FA_BLK * LD];      // dO
+    __shared__ float Ls[FA_BLK], Ds[FA_BLK];
+    const int nkb = (p.T + FA_BLK - 1) / FA_BLK;
+    int bid = blockIdx.x;
+    const int kb = bid % nkb; bid /= nkb;                               // early key blocks are the heaviest: first
+    const int hd = bid % p.h;
+    const long long b = bid / p.h;
+    const int T = p.T, d = p.d, hoff = hd * DH;
+    const long long bt0 = b * T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int k_abs = kb * FA_BLK + wv * 16 + li;                       // this lane's key (column of S)
+    const float scale = rsqrtf((float)DH);
+    const long long bh = b * p.h + hd;
+
+    float4 kf[NC], vf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        kf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vf[c] = kf[c];
+        if (k_abs < T) {
+            kf[c] = *reinterpret_cast<const float4*>(p.k + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g);
+            vf[c] = *reinterpret_cast<const float4*>(p.v + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g);
+        }
+    }
+    f32x4_t dk[NC], dv[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { dk[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[c] = dk[c]; }
+    const uint32_t thr = drop_thresh(p.p);
+    const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
+
+    for (int qt = kb; qt < nkb; ++qt) {
+        __syncthreads();
+        fa_load_tile<DH>(Qs, p.q, bt0, qt * FA_BLK, T, d, hoff, scale);
+        fa_load_tile<DH>(Gs, p.dO, bt0, qt * FA_BLK, T, d, hoff, 1.f);
+        if (threadIdx.x < FA_BLK) {
+            const int qq = qt * FA_BLK + threadIdx.x;
+            Ls[threadIdx.x] = qq < T ? p.lse[bh * T + qq] : 0.f;
+            Ds[threadIdx.x] = qq < T ? p.delta[bh * T + qq] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(Qs + (16 * sq + li) * LD + 16 * c + 4 * g);
+                s = MFMA16(a.x, kf[c].x, s);
+                s = MFMA16(a.y, kf[c].y, s);
+                s = MFMA16(a.z, kf[c].z, s);
+                s = MFMA16(a.w, kf[c].w, s);
+                const float4 e = *reinterpret_cast<const float4*>(Gs + (16 * sq + li) * LD + 16 * c + 4 * g);
+                dp = MFMA16(e.x, vf[c].x, dp);
+                dp = MFMA16(e.y, vf[c].y, dp);
+                dp = MFMA16(e.z, vf[c].z, dp);
+                dp = MFMA16(e.w, vf[c].w, dp);
+            }
+            // s[r] = S[query 16*sq+4g+r][key k_abs], dp[r] likewise
+            f32x4_t pd, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = 16 * sq + 4 * g + r;
+                const int qa = qt * FA_BLK + ql;
+                float pr = 0.f;
+                if (qa < T && k_abs <= qa && k_abs < T) pr = __expf(s[r] - Ls[ql]);
+                float keep = 1.f;
+                if (p.p > 0.f) {
+                    const uint64_t idx = ((uint64_t)bh * T + (uint64_t)(qa < T ? qa : 0)) * T + (uint64_t)(k_abs < T ? k_abs : 0);
+                    keep = rng_keep(rng_bits4(p.seed, p.site, idx >> 2), (int)(idx & 3), thr) ? dsc : 0.f;
+                }
+                pd[r] = pr * keep;
+                ds[r] = pr * (dp[r] * keep - Ds[ql]);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ag = Gs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
+                    dv[c] = MFMA16(ag, pd[r], dv[c]);
+                    const float aq = Qs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
+                    dk[c] = MFMA16(aq, ds[r], dk[c]);
+                }
+        }
+    }
+    if (k_abs < T) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            *reinterpret_cast<float4*>(p.dv + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
+            *reinterpret_cast<float4*>(p.dk + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g) = make_float4(dk[c][0], dk[c][1], dk[c][2], dk[c][3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward: dQ
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
+    constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD;
+    __shared__ __attribute__((aligned(16))) float Ks[FA_BLK * LD];
+    __shared__ __attribute__((aligned(16))) float Vs[FA_BLK * LD];
+    const int nqb = (p.T + FA_BLK - 1) / FA_BLK;
+    int bid = blockIdx.x;
+    const int qb = nqb - 1 - (bid % nqb); bid /= nqb;
+    const int hd = bid % p.h;
+    const long long b = bid / p.h;
+    const int T = p.T, d = p.d, hoff = hd * DH;
+    const long long bt0 = b * T;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int q_abs = qb * FA_BLK + wv * 16 + li;
+    const float scale = rsqrtf((float)DH);
+    const long long bh = b * p.h + hd;
+
+    float4 qf[NC], gf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        qf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gf[c] = qf[c];
+        if (q_abs < T) {
+            const float4 v = *reinterpret_cast<const float4*>(p.q + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g);
+            qf[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+            gf[c] = *reinterpret_cast<const float4*>(p.dO + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g);
+        }
+    }
+    const float lse = q_abs < T ? p.lse[bh * T + q_abs] : 0.f;
+    const float dlt = q_abs < T ? p.delta[bh * T + q_abs] : 0.f;
+    f32x4_t dq[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dq[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const uint32_t thr = drop_thresh(p.p);
+    const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
+
+    for (int kt = 0; kt <= qb; ++kt) {
+        __syncthreads();
+        fa_load_tile<DH>(Ks, p.k, bt0, kt * FA_BLK, T, d, hoff, 1.f);
+        fa_load_tile<DH>(Vs, p.v, bt0, kt * FA_BLK, T, d, hoff, 1.f);
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 a = *reinterpret_cast<const float4*>(Ks + (16 * st + li) * LD + 16 * c + 4 * g);
+                s = MFMA16(a.x, qf[c].x, s);
+                s = MFMA16(a.y, qf[c].y, s);
+                s = MFMA16(a.z, qf[c].z, s);
+                s = MFMA16(a.w, qf[c].w, s);
+                const float4 e = *reinterpret_cast<const float4*>(Vs + (16 * st + li) * LD + 16 * c + 4 * g);
+                dp = MFMA16(e.x, gf[c].x, dp);
+                dp = MFMA16(e.y, gf[c].y, dp);
+                dp = MFMA16(e.z, gf[c].z, dp);
+                dp = MFMA16(e.w, gf[c].w, dp);
+            }
+            const int key0 = kt * FA_BLK + 16 * st + 4 * g;
+            uint2 bits = make_uint2(0u, 0u);
+            if (p.p > 0.f) {
+                const uint64_t idx = ((uint64_t)bh * T + (uint64_t)(q_abs < T ? q_abs : 0)) * T + (uint64_t)key0;
+                bits = rng_bits4(p.seed, p.site, idx >> 2);
+            }
+            f32x4_t ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = 0.f;
+                if (q_abs < T && key0 + r <= q_abs && key0 + r < T) pr = __expf(s[r] - lse);
+                float keep = 1.f;
+                if (p.p > 0.f) keep = rng_keep(bits, r, thr) ? dsc : 0.f;
+                ds[r] = pr * (dp[r] * keep - dlt);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = Ks[(16 * st + 4 * g + r) * LD + 16 * c + li];
+                    dq[c] = MFMA16(a, ds[r], dq[c]);
+                }
+        }
+    }
+    if (q_abs < T) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            *reinterpret_cast<float4*>(p.dq + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g) =
+                make_float4(dq[c][0] * scale, dq[c][1] * scale, dq[c][2] * scale, dq[c][3] * scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- launchers
+template <int DH>
+static int attn_launch_dh(const AttnArgs& a, int mode, hipStream_t st) {
+    const int nblk = cdiv(a.T, FA_BLK);
+    const dim3 grid(a.B * a.h * nblk), blk(256);
+    if (mode == 0) {
+        hipLaunchKernelGGL((attn_fwd_kernel<DH>), grid, blk, 0, st, a);
+        OCRL_CHECK_LAUNCH("attn_fwd");
+    } else {
+        const long long BT = (long long)a.B * a.T;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(BT * a.h, 256)), dim3(256), 0, st, a.dO, a.o, a.delta, BT, a.T, a.d, a.h);
+        OCRL_CHECK_LAUNCH("attn_delta");
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<DH>), grid, blk, 0, st, a);
+        OCRL_CHECK_LAUNCH("attn_bwd_kv");
+        hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, blk, 0, st, a);
+        OCRL_CHECK_LAUNCH("attn_bwd_q");
+    }
+    return 0;
+}
+
+// mode 0: forward (q,k,v -> o, lse);  mode 1: backward (q,k,v,o,lse,dO -> dq,dk,dv; delta is scratch [B,h,T])
+int attn_launch(const AttnArgs& a, int mode, hipStream_t st) {
+    OCRL_REQUIRE(a.B > 0 && a.T > 0 && a.h > 0 && a.d % a.h == 0, "attention: bad shape");
+    OCRL_REQUIRE(a.q && a.k && a.v && a.o && a.lse, "attention: missing buffers");
+    if (mode) OCRL_REQUIRE(a.dO && a.dq && a.dk && a.dv && a.delta, "attention backward: missing buffers");
+    OCRL_REQUIRE((long long)a.T * a.T * a.B * a.h < (1ll << 62), "attention: too large");
+    const int pi = prof_begin(mode ? PROF_ATTN_BWD : PROF_ATTN_FWD, st);
+    int rc;
+    switch (a.d / a.h) {
+        case 16: rc = attn_launch_dh<16>(a, mode, st); break;
+        case 32: rc = attn_launch_dh<32>(a, mode, st); break;
+        case 48: rc = attn_launch_dh<48>(a, mode, st); break;
+        case 64: rc = attn_launch_dh<64>(a, mode, st); break;
+        default: ocrl_set_error("attention: head dim %d unsupported (16/32/48/64)", a.d / a.h); return 1;
+    }
+    prof_end(pi, st);
+    return rc;
+}

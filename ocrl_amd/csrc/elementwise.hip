@@ -533,13 +533,16 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
         if (c < dh) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
 }
 
-// backward: dQ [B,T,d] written; dKm/dVm [B,K,d] accumulated with atomics (must be zeroed by the caller)
+// backward: dQ [B,T,d] written; dKm/dVm [B,K,d] accumulated with one atomic per (wave, slot, channel)
+// (must be zeroed by the caller).  The per-query outer products are reduced over the 64 queries of a wave
+// through a wave-private LDS staging tile (queries x (K + dh)), not through contended atomics.
+#define CA_SW (CA_MAXK + CA_MAXDH + 1)
 __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
                                                              const float* __restrict__ Km, const float* __restrict__ Vm,
                                                              const float* __restrict__ P, float* __restrict__ dQ,
                                                              float* __restrict__ dKm, float* __restrict__ dVm, int T, int K, int d,
                                                              int h, float p, unsigned long long seed, unsigned site) {
-    extern __shared__ float sm[];   // Ks, Vs, dKs, dVs  [K][dh] each
+    extern __shared__ float sm[];   // Ks [K][dh], Vs [K][dh], stage [4][64][CA_SW]
     const int dh = d / h;
     const int nqb = (T + 255) / 256;
     int bid = blockIdx.x;
@@ -548,30 +551,37 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     const long long b = bid / h;
     float* Ks = sm;
     float* Vs = sm + K * dh;
-    float* dKs = sm + 2 * K * dh;
-    float* dVs = sm + 3 * K * dh;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* stg = sm + 2 * K * dh + wv * 64 * CA_SW;      // this wave's staging tile
     for (int i = threadIdx.x; i < K * dh; i += 256) {
         const int k = i / dh, c = i % dh;
         Ks[i] = Km[(b * K + k) * d + hd * dh + c];
         Vs[i] = Vm[(b * K + k) * d + hd * dh + c];
-        dKs[i] = 0.f;
-        dVs[i] = 0.f;
     }
     __syncthreads();
     const int q = qb * 256 + threadIdx.x;
-    if (q < T) {
-        const float scale = rsqrtf((float)dh);
-        float qv[CA_MAXDH], go[CA_MAXDH], dq[CA_MAXDH];
+    const bool act = q < T;
+    const float scale = rsqrtf((float)dh);
+    float qv[CA_MAXDH], go[CA_MAXDH];
+    float pr[CA_MAXK], dp[CA_MAXK], keepv[CA_MAXK];
+#pragma unroll
+    for (int c = 0; c < CA_MAXDH; ++c) { qv[c] = 0.f; go[c] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < CA_MAXK; ++k) { pr[k] = 0.f; dp[k] = 0.f; keepv[k] = 0.f; }
+    float delta = 0.f;
+    if (act) {
         const float* qp = Q + (b * T + q) * d + hd * dh;
         const float* gp = dO + (b * T + q) * d + hd * dh;
 #pragma unroll
-        for (int c = 0; c < CA_MAXDH; ++c)
-            if (c < dh) { qv[c] = qp[c] * scale; go[c] = gp[c]; dq[c] = 0.f; }
+        for (int c = 0; c < CA_MAXDH; c += 4)
+            if (c < dh) {
+                const float4 a = *reinterpret_cast<const float4*>(qp + c), g = *reinterpret_cast<const float4*>(gp + c);
+                qv[c] = a.x * scale; qv[c + 1] = a.y * scale; qv[c + 2] = a.z * scale; qv[c + 3] = a.w * scale;
+                go[c] = g.x; go[c + 1] = g.y; go[c + 2] = g.z; go[c + 3] = g.w;
+            }
         const uint32_t thr = drop_thresh(p);
         const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
         const long long prow = ((b * h + hd) * T + q) * K;
-        float pr[CA_MAXK], dp[CA_MAXK];
-        float delta = 0.f;
 #pragma unroll
         for (int k = 0; k < CA_MAXK; ++k)
             if (k < K) {
@@ -581,38 +591,58 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
                     const uint64_t idx = (uint64_t)prow + k;
                     keep = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? sc : 0.f;
                 }
+                keepv[k] = keep;
                 float a = 0.f;
 #pragma unroll
                 for (int c = 0; c < CA_MAXDH; ++c)
                     if (c < dh) a += go[c] * Vs[k * dh + c];
                 dp[k] = a * keep;
                 delta += pr[k] * dp[k];
-                const float pd = pr[k] * keep;
-#pragma unroll
-                for (int c = 0; c < CA_MAXDH; ++c)
-                    if (c < dh) atomicAdd(&dVs[k * dh + c], pd * go[c]);
             }
+    }
+    // ---- dV[k][c] += sum_q pd[q][k] * go[q][c]
 #pragma unroll
-        for (int k = 0; k < CA_MAXK; ++k)
-            if (k < K) {
-                const float ds = pr[k] * (dp[k] - delta);
+    for (int k = 0; k < CA_MAXK; ++k) stg[lane * CA_SW + k] = pr[k] * keepv[k];
 #pragma unroll
-                for (int c = 0; c < CA_MAXDH; ++c)
-                    if (c < dh) {
-                        dq[c] += ds * Ks[k * dh + c];
-                        atomicAdd(&dKs[k * dh + c], ds * qv[c]);
-                    }
-            }
-        float* dqp = dQ + (b * T + q) * d + hd * dh;
-#pragma unroll
-        for (int c = 0; c < CA_MAXDH; ++c)
-            if (c < dh) dqp[c] = dq[c] * scale;
+    for (int c = 0; c < CA_MAXDH; ++c)
+        if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = go[c];
+    __syncthreads();
+    for (int o = lane; o < K * dh; o += 64) {
+        const int k = o / dh, c = o - k * dh;
+        float a = 0.f;
+        for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
+        atomicAdd(&dVm[(b * K + k) * d + hd * dh + c], a);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K * dh; i += 256) {
-        const int k = i / dh, c = i % dh;
-        atomicAdd(&dKm[(b * K + k) * d + hd * dh + c], dKs[i]);
-        atomicAdd(&dVm[(b * K + k) * d + hd * dh + c], dVs[i]);
+    // ---- dS, dQ, and dK[k][c] += sum_q ds[q][k] * q'[q][c]
+    float dq[CA_MAXDH];
+#pragma unroll
+    for (int c = 0; c < CA_MAXDH; ++c) dq[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < CA_MAXK; ++k) {
+        const float ds = (k < K) ? pr[k] * (dp[k] - delta) : 0.f;
+        stg[lane * CA_SW + k] = ds;
+        if (k < K) {
+#pragma unroll
+            for (int c = 0; c < CA_MAXDH; ++c)
+                if (c < dh) dq[c] += ds * Ks[k * dh + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CA_MAXDH; ++c)
+        if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = qv[c];
+    __syncthreads();
+    for (int o = lane; o < K * dh; o += 64) {
+        const int k = o / dh, c = o - k * dh;
+        float a = 0.f;
+        for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
+        atomicAdd(&dKm[(b * K + k) * d + hd * dh + c], a);
+    }
+    if (act) {
+        float* dqp = dQ + (b * T + q) * d + hd * dh;
+#pragma unroll
+        for (int c = 0; c < CA_MAXDH; c += 4)
+            if (c < dh) *reinterpret_cast<float4*>(dqp + c) = make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale);
     }
 }
 
@@ -831,7 +861,13 @@ int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, cons
                           int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st) {
     OCRL_REQUIRE(K <= CA_MAXK && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
     const int grid = B * h * cdiv(T, 256);
-    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3(grid), dim3(256), 4 * K * (d / h) * 4, st, dO, Q, Km, Vm, P, dQ, dKm, dVm, T, K, d, h, p, seed, site);
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)cross_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (2 * CA_MAXK * CA_MAXDH + 4 * 64 * CA_SW) * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3(grid), dim3(256), (2 * K * (d / h) + 4 * 64 * CA_SW) * 4, st, dO, Q, Km, Vm, P, dQ, dKm, dVm, T, K, d, h, p, seed, site);
     OCRL_CHECK_LAUNCH("cross_attn_bwd");
     return 0;
 }

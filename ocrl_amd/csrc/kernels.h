@@ -4,7 +4,7 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ prof.cpp
-enum { PROF_CONV5 = 0, PROF_CONV_OTHER = 1, PROF_WGRAD = 2, PROF_GEMM = 3, PROF_SA_FWD = 4, PROF_SA_BWD = 5, PROF_NTAGS = 6 };
+enum { PROF_CONV5 = 0, PROF_CONV_OTHER = 1, PROF_WGRAD = 2, PROF_GEMM = 3, PROF_SA_FWD = 4, PROF_SA_BWD = 5, PROF_ATTN_FWD = 6, PROF_ATTN_BWD = 7, PROF_NTAGS = 8 };
 int prof_begin(int tag, hipStream_t st);
 void prof_end(int idx, hipStream_t st);
 
@@ -152,3 +152,17 @@ int clip_adam_launch(float* p, const float* g, float* m, float* v, long long n, 
 int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st);
 int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float* noise, float* dmu, float* dlogsig, int BK, int D, unsigned long long seed, hipStream_t st);
 int copy_launch(const float* src, float* dst, long long n, hipStream_t st);
+
+// ------------------------------------------------------------------ attention.hip
+struct AttnArgs {
+    const float *q = nullptr, *k = nullptr, *v = nullptr;   // [B,T,d] projected (q unscaled), heads side by side
+    float* o = nullptr;                                     // [B,T,d]
+    float* lse = nullptr;                                   // [B,h,T] log-sum-exp of the scaled scores
+    int B = 0, T = 0, d = 0, h = 0;
+    float p = 0.f;                                          // dropout on the probabilities
+    unsigned long long seed = 0;
+    unsigned site = 0;
+    const float* dO = nullptr;                              // backward
+    float *dq = nullptr, *dk = nullptr, *dv = nullptr, *delta = nullptr;
+};
+int attn_launch(const AttnArgs& a, int mode, hipStream_t st);

@@ -157,19 +157,18 @@ void SlateModel::layout_workspace(bool commit) {
     for (int i = 0; i < 2; ++i) { dw_fwd_[i] = carve(nullptr, 9 * 64 * 64); dw_bwd_[i] = carve(nullptr, 9 * 64 * 64); }
     w11p_ = carve(nullptr, 4 * 64);
     mem_ = carve("mem", BK * d); emb_ = carve("emb", BT * d);
-    const size_t att = B * NH * (size_t)T * T;
     for (int b = 0; b < NB; ++b) {
         Blk& k = blk_[b];
         k.ln1 = carve(nullptr, BT * d); k.ln1_mean = carve(nullptr, BT); k.ln1_rstd = carve(nullptr, BT);
         k.q = carve(nullptr, BT * d); k.k = carve(nullptr, BT * d); k.v = carve(nullptr, BT * d);
-        k.P = carve(nullptr, att); k.ao = carve(nullptr, BT * d); k.x1 = carve(nullptr, BT * d);
+        k.lse = carve(nullptr, B * NH * (size_t)T); k.ao = carve(nullptr, BT * d); k.x1 = carve(nullptr, BT * d);
         k.ln2 = carve(nullptr, BT * d); k.ln2_mean = carve(nullptr, BT); k.ln2_rstd = carve(nullptr, BT);
         k.cq = carve(nullptr, BT * d); k.ck = carve(nullptr, BK * d); k.cv = carve(nullptr, BK * d);
         k.cP = carve(nullptr, B * NH * (size_t)T * K); k.cao = carve(nullptr, BT * d); k.x2 = carve(nullptr, BT * d);
         k.ln3 = carve(nullptr, BT * d); k.ln3_mean = carve(nullptr, BT); k.ln3_rstd = carve(nullptr, BT);
         k.f1 = carve(nullptr, BT * 4 * d); k.x3 = carve(nullptr, BT * d);
     }
-    Pd_ = carve(nullptr, att); dP_ = carve(nullptr, att);
+    attn_delta_ = carve(nullptr, B * NH * (size_t)T);
     lnf_ = carve("dec_out", BT * d); lnf_mean_ = carve(nullptr, BT); lnf_rstd_ = carve(nullptr, BT);
     pred_ = carve("pred", BT * V);
     gx_ = carve(nullptr, BT * d); gbr_ = carve(nullptr, BT * d); gt1_ = carve(nullptr, BT * d); gt2_ = carve(nullptr, BT * d);
@@ -378,21 +377,11 @@ int SlateModel::fwd_decoder(hipStream_t st) {
         RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_q.weight"), nullptr, k.q, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
         RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_k.weight"), nullptr, k.k, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
         RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_v.weight"), nullptr, k.v, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
-        {   // scores = (q * dh^-0.5) k^T per (image, head)
-            GemmArgs a;
-            a.A = k.q; a.B = k.k; a.C = k.P; a.M = T; a.N = T; a.K = DH; a.lda = d; a.ldb = d; a.ldc = T; a.akc = 1; a.bkc = 1;
-            a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)T * d; a.sAi = DH; a.sB = (long long)T * d; a.sBi = DH;
-            a.sC = (long long)NH * T * T; a.sCi = (long long)T * T; a.alpha = scale;
-            RC(gemm_launch(a, st));
-        }
-        float* Pd = p > 0.f ? Pd_ : k.P;
-        RC(softmax_causal_fwd_launch(k.P, Pd, (long long)B * NH, T, p, last_.seed, site + 0, st));
-        {   // ao = dropout(P) v
-            GemmArgs a;
-            a.A = Pd; a.B = k.v; a.C = k.ao; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 1; a.bkc = 0;
-            a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
-            a.sC = (long long)T * d; a.sCi = DH;
-            RC(gemm_launch(a, st));
+        {   // causal self attention, flash style (scores never leave the chip)
+            AttnArgs a;
+            a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH;
+            a.p = p; a.seed = last_.seed; a.site = site + 0;
+            RC(attn_launch(a, 0, st));
         }
         RC(lin_fwd(k.ao, d, P(pre + "self_attn.proj_o.weight"), nullptr, k.x1, d, BT, d, d, 0, res, d, p, site + 1, st));
         // cross attention to the projected slots
@@ -489,48 +478,26 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 1, st)); gb = gbr_; }
         RC(lin_bwd_w(gb, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
         RC(lin_bwd_x(gb, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt1 = d ao
-        const float* Pd = k.P;
-        if (p > 0.f) { RC(dropout_apply_launch(k.P, Pd_, (long long)B * NH * T * T, p, last_.seed, site + 0, st)); Pd = Pd_; }
-        GemmArgs a;
-        // dPd = d ao_h v_h^T
-        a = GemmArgs();
-        a.A = gt1_; a.B = k.v; a.C = dP_; a.M = T; a.N = T; a.K = DH; a.lda = d; a.ldb = d; a.ldc = T; a.akc = 1; a.bkc = 1;
-        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)T * d; a.sAi = DH; a.sB = (long long)T * d; a.sBi = DH;
-        a.sC = (long long)NH * T * T; a.sCi = (long long)T * T;
-        RC(gemm_launch(a, st));
-        // dv_h = Pd^T d ao_h
-        a = GemmArgs();
-        a.A = Pd; a.B = gt1_; a.C = gt3_; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 0; a.bkc = 0;
-        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
-        a.sC = (long long)T * d; a.sCi = DH;
-        RC(gemm_launch(a, st));                                                                  // gt3 = dv
-        RC(softmax_causal_bwd_launch(k.P, dP_, (long long)B * NH, T, p, last_.seed, site + 0, st));   // dP_ <- dS
-        RC(lin_bwd_w(gt3_, d, k.ln1, d, G(pre + "self_attn.proj_v.weight"), nullptr, BT, d, d, 1.f, st));
-        // d ln1 accumulates the three projections; start with v
-        RC(lin_bwd_x(gt3_, d, P(pre + "self_attn.proj_v.weight"), gt2_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt2 = d ln1 (v part)
-        // dq_h = scale dS k_h
-        a = GemmArgs();
-        a.A = dP_; a.B = k.k; a.C = gt1_; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 1; a.bkc = 0;
-        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
-        a.sC = (long long)T * d; a.sCi = DH; a.alpha = scale;
-        RC(gemm_launch(a, st));                                                                  // gt1 = dq
-        // dk_h = scale dS^T q_h
-        a = GemmArgs();
-        a.A = dP_; a.B = k.q; a.C = gt3_; a.M = T; a.N = DH; a.K = T; a.lda = T; a.ldb = d; a.ldc = d; a.akc = 0; a.bkc = 0;
-        a.batch = B * NH; a.batch_inner = NH; a.sA = (long long)NH * T * T; a.sAi = (long long)T * T; a.sB = (long long)T * d; a.sBi = DH;
-        a.sC = (long long)T * d; a.sCi = DH; a.alpha = scale;
-        RC(gemm_launch(a, st));                                                                  // gt3 = dk
-        RC(lin_bwd_w(gt1_, d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
+        {
+            AttnArgs a;
+            a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH;
+            a.p = p; a.seed = last_.seed; a.site = site + 0;
+            a.dO = gt1_; a.dq = gt2_; a.dk = gt3_; a.dv = gbr_; a.delta = attn_delta_;
+            RC(attn_launch(a, 1, st));
+        }
+        RC(lin_bwd_w(gt2_, d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
         RC(lin_bwd_w(gt3_, d, k.ln1, d, G(pre + "self_attn.proj_k.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_x(gt1_, d, P(pre + "self_attn.proj_q.weight"), gt2_, d, BT, d, d, nullptr, 0, gt2_, d, st));
-        RC(lin_bwd_x(gt3_, d, P(pre + "self_attn.proj_k.weight"), gt2_, d, BT, d, d, nullptr, 0, gt2_, d, st));      // gt2 = d ln1
+        RC(lin_bwd_w(gbr_, d, k.ln1, d, G(pre + "self_attn.proj_v.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gt2_, d, P(pre + "self_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));
+        RC(lin_bwd_x(gt3_, d, P(pre + "self_attn.proj_k.weight"), gt1_, d, BT, d, d, nullptr, 0, gt1_, d, st));
+        RC(lin_bwd_x(gbr_, d, P(pre + "self_attn.proj_v.weight"), gt1_, d, BT, d, d, nullptr, 0, gt1_, d, st));      // gt1 = d ln1
         if (b == 0) {
             // ln1 is both the attention input and the residual stream: d ln1_total = gx + gt2, then LN backward to emb
-            RC(axpy_launch(gx_, gt2_, BT * d, 1.f, st));
-            RC(layernorm_bwd_launch(gt2_, xin, k.ln1_mean, k.ln1_rstd, P(pre + "self_attn_layer_norm.weight"), gx_,
+            RC(axpy_launch(gx_, gt1_, BT * d, 1.f, st));
+            RC(layernorm_bwd_launch(gt1_, xin, k.ln1_mean, k.ln1_rstd, P(pre + "self_attn_layer_norm.weight"), gx_,
                                     G(pre + "self_attn_layer_norm.weight"), BT, d, 0, 0, scratch_, scratch_floats_, st));
         } else {
-            RC(layernorm_bwd_launch(gt2_, xin, k.ln1_mean, k.ln1_rstd, P(pre + "self_attn_layer_norm.weight"), gx_,
+            RC(layernorm_bwd_launch(gt1_, xin, k.ln1_mean, k.ln1_rstd, P(pre + "self_attn_layer_norm.weight"), gx_,
                                     G(pre + "self_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         }
     }

@@ -109,12 +109,12 @@ private:
     float *w11p_;                         // [4,64] padded copy of the dVAE output conv
     float *mem_, *emb_;
     struct Blk {
-        float *ln1, *ln1_mean, *ln1_rstd, *q, *k, *v, *P, *ao, *x1;
+        float *ln1, *ln1_mean, *ln1_rstd, *q, *k, *v, *lse, *ao, *x1;
         float *ln2, *ln2_mean, *ln2_rstd, *cq, *ck, *cv, *cP, *cao, *x2;
         float *ln3, *ln3_mean, *ln3_rstd, *f1, *x3;
     };
     std::vector<Blk> blk_;
-    float *Pd_, *dP_;                     // shared [B*h,T,T] temporaries
+    float *attn_delta_;                   // [B,h,T] scratch of the attention backward
     float *lnf_, *lnf_mean_, *lnf_rstd_, *pred_;
     // gradient temporaries
     float *gx_, *gbr_, *gt1_, *gt2_, *gt3_, *gf1_, *gmem_, *gck_, *gcv_, *gslots_, *gslots0_;

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 SMALL = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2)
 MID = dict(obs_size=32, vocab_size=512, num_slots=5, num_iterations=2, num_dec_blocks=2)
+LONG = dict(obs_size=64, vocab_size=256, num_slots=4, num_iterations=1, num_dec_blocks=1)     # T = 256: four causal key tiles
 
 
 def make_engine(cfg, B):
@@ -77,7 +78,7 @@ def compare_grads(tag, eng, trainer):
     return worst, rows
 
 
-@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3)])
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2)])
 def test_forward_backward_eval(tag, over, B):
     """dropout off: every stage of the forward, then every parameter gradient"""
     cfg = O.default_cfg(**over)
@@ -105,9 +106,10 @@ def test_forward_backward_eval(tag, over, B):
     assert worst < 1e-3, rows[:5]
 
 
-def test_train_mode_dropout_parity():
+@pytest.mark.parametrize("over", [SMALL, LONG])
+def test_train_mode_dropout_parity(over):
     """train mode: the oracle consumes the exact keep-masks the kernels derived from the seed"""
-    cfg = O.default_cfg(**SMALL)
+    cfg = O.default_cfg(**over)
     B = 2
     P = O.formula_params(cfg)
     eng = make_engine(cfg, B)
