@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int qb = nqb - 1 - (bid % nqb); bid /= nqb;       // heaviest (last) query blocks first
     const int hd = bid % p.h;
     const long long b = bid / p.h;
-    const int T = p.T, d = p.d, hoff = hd * DH;
+    const int T = p.T, d = p.ld, hoff = hd * DH;
     const long long bt0 = b * T;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         const float inv = 1.0f / l;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-            *reinterpret_cast<float4*>(p.o + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g) = make_float4(o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv);
+            *reinterpret_cast<float4*>(p.o + (bt0 + q_abs) * p.d + hoff + 16 * c + 4 * g) = make_float4(o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv);
         if (g == 0) p.lse[bh * T + q_abs] = m + __logf(l);
     }
 }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
     const int kb = bid % nkb; bid /= nkb;                               // early key blocks are the heaviest: first
     const int hd = bid % p.h;
     const long long b = bid / p.h;
-    const int T = p.T, d = p.d, hoff = hd * DH;
+    const int T = p.T, d = p.ld, hoff = hd * DH;
     const long long bt0 = b * T;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
     for (int qt = kb; qt < nkb; ++qt) {
         __syncthreads();
         fa_load_tile<DH>(Qs, p.q, bt0, qt * FA_BLK, T, d, hoff, scale);
-        fa_load_tile<DH>(Gs, p.dO, bt0, qt * FA_BLK, T, d, hoff, 1.f);
+        fa_load_tile<DH>(Gs, p.dO, bt0, qt * FA_BLK, T, p.d, hoff, 1.f);
         if (threadIdx.x < FA_BLK) {
             const int qq = qt * FA_BLK + threadIdx.x;
             Ls[threadIdx.x] = qq < T ? p.lse[bh * T + qq] : 0.f;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
     const int qb = nqb - 1 - (bid % nqb); bid /= nqb;
     const int hd = bid % p.h;
     const long long b = bid / p.h;
-    const int T = p.T, d = p.d, hoff = hd * DH;
+    const int T = p.T, d = p.ld, hoff = hd * DH;
     const long long bt0 = b * T;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
         if (q_abs < T) {
             const float4 v = *reinterpret_cast<const float4*>(p.q + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g);
             qf[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
-            gf[c] = *reinterpret_cast<const float4*>(p.dO + (bt0 + q_abs) * d + hoff + 16 * c + 4 * g);
+            gf[c] = *reinterpret_cast<const float4*>(p.dO + (bt0 + q_abs) * p.d + hoff + 16 * c + 4 * g);
         }
     }
     const float lse = q_abs < T ? p.lse[bh * T + q_abs] : 0.f;
@@ -374,7 +374,7 @@ static int attn_launch_dh(const AttnArgs& a, int mode, hipStream_t st) {
 
 // mode 0: forward (q,k,v -> o, lse);  mode 1: backward (q,k,v,o,lse,dO -> dq,dk,dv; delta is scratch [B,h,T])
 int attn_launch(const AttnArgs& a, int mode, hipStream_t st) {
-    OCRL_REQUIRE(a.B > 0 && a.T > 0 && a.h > 0 && a.d % a.h == 0, "attention: bad shape");
+    OCRL_REQUIRE(a.B > 0 && a.T > 0 && a.h > 0 && a.d % a.h == 0 && a.ld >= a.d && a.ld % 4 == 0, "attention: bad shape");
     OCRL_REQUIRE(a.q && a.k && a.v && a.o && a.lse, "attention: missing buffers");
     if (mode) OCRL_REQUIRE(a.dO && a.dq && a.dk && a.dv && a.delta, "attention backward: missing buffers");
     OCRL_REQUIRE((long long)a.T * a.T * a.B * a.h < (1ll << 62), "attention: too large");

@@ -271,7 +271,7 @@ static int conv_wgrad_cfg(const WgradArgs& a, int nchunk, hipStream_t st) {
 
 int conv_wgrad_chunks(int B, int H, int W, int KS) {
     const int ntiles = cdiv(W, TW) * cdiv(H, TH) * B;
-    int n = (2 * 256 + KS - 1) / KS;
+    int n = (2 * 256) / KS;          // all workgroups co-resident (2 per CU): no straggler round
     return n < ntiles ? n : ntiles;
 }
 size_t conv_wgrad_ws_floats(int B, int H, int W, int KS, int CIN) {

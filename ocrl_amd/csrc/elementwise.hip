@@ -159,13 +159,24 @@ __global__ void colsum_kernel(const float* __restrict__ X, long long ld, float* 
     __syncthreads();
     if (rl == 0 && col < F) part[(size_t)blockIdx.y * F + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int F, int accumulate, float scale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= F) return;
+// out[c] (+)= scale * sum_k part[k][c]: 64 columns x 16 partial-row lanes per block (the partials are read in
+// parallel, not as one serial chain per column)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int F, int accumulate, float scale) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * F + c];
-    s *= scale;
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < F)
+        for (int k = rl; k < nchunk; k += 16) s += part[(size_t)k * F + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < F) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        t *= scale;
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // out[0] (+)= scale * sum(part[0..n))   — single block, deterministic
@@ -761,7 +772,7 @@ int colsum_launch(const float* X, long long ld, float* out, long long R, int F, 
     const long long rpc = (R + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, (int)nchunk), dim3(256), 0, st, X, ld, ws, R, F, rpc);
     OCRL_CHECK_LAUNCH("colsum");
-    hipLaunchKernelGGL(colsum_final_kernel, GRID1D(F), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 64)), dim3(1024), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
     OCRL_CHECK_LAUNCH("colsum_final");
     return 0;
 }

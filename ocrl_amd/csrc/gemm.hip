@@ -207,24 +207,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i]
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n,
-                                     int splits, long long stride, int accumulate) {
-    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 4 <= n) {
-        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
-        for (int k = 0; k < splits; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + i);
+// out[i] = (accumulate ? out[i] : 0) + sum_s part[s*stride + i]   (n % 4 == 0)
+// block = 16 float4 columns x 16 split lanes: the slabs are read in parallel and combined through LDS.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n4,
+                                                            int splits, long long stride, int accumulate) {
+    __shared__ float4 red[16][16];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const long long i = (long long)blockIdx.x * 16 + cl;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4)
+        for (int k = sl; k < splits; k += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + i * 4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        *reinterpret_cast<float4*>(out + i) = s;
-    } else {
-        for (long long e = i; e < n; ++e) {
-            float s = accumulate ? out[e] : 0.f;
-            for (int k = 0; k < splits; ++k) s += part[(size_t)k * stride + e];
-            out[e] = s;
-        }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+        float4 t = accumulate ? *reinterpret_cast<const float4*>(out + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t.x += red[k][cl].x; t.y += red[k][cl].y; t.z += red[k][cl].z; t.w += red[k][cl].w; }
+        *reinterpret_cast<float4*>(out + i * 4) = t;
     }
 }
 
@@ -299,8 +301,9 @@ int gemm_launch(const GemmArgs& a_in, hipStream_t st) {
 
 int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
                          int accumulate, hipStream_t st) {
-    const long long thr = (n + 3) / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(thr, 256)), dim3(256), 0, st, part, out, n, splits, stride, accumulate);
+    OCRL_REQUIRE(n % 4 == 0 && stride % 4 == 0, "splitk_reduce: n and stride must be multiples of 4");
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n4, 16)), dim3(256), 0, st, part, out, n4, splits, stride, accumulate);
     OCRL_CHECK_LAUNCH("splitk_reduce");
     return 0;
 }

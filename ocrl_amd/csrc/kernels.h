@@ -155,10 +155,11 @@ int copy_launch(const float* src, float* dst, long long n, hipStream_t st);
 
 // ------------------------------------------------------------------ attention.hip
 struct AttnArgs {
-    const float *q = nullptr, *k = nullptr, *v = nullptr;   // [B,T,d] projected (q unscaled), heads side by side
+    const float *q = nullptr, *k = nullptr, *v = nullptr;   // projected (q unscaled), heads side by side, row stride ld (>= d)
     float* o = nullptr;                                     // [B,T,d]
     float* lse = nullptr;                                   // [B,h,T] log-sum-exp of the scaled scores
     int B = 0, T = 0, d = 0, h = 0;
+    int ld = 0;                                             // row stride of q,k,v and dq,dk,dv (o, dO are dense [B,T,d])
     float p = 0.f;                                          // dropout on the probabilities
     unsigned long long seed = 0;
     unsigned site = 0;

@@ -160,7 +160,7 @@ void SlateModel::layout_workspace(bool commit) {
     for (int b = 0; b < NB; ++b) {
         Blk& k = blk_[b];
         k.ln1 = carve(nullptr, BT * d); k.ln1_mean = carve(nullptr, BT); k.ln1_rstd = carve(nullptr, BT);
-        k.q = carve(nullptr, BT * d); k.k = carve(nullptr, BT * d); k.v = carve(nullptr, BT * d);
+        k.q = carve(nullptr, BT * 3 * d); k.k = k.q + d; k.v = k.q + 2 * d;      // fused [BT, 3d] projection output
         k.lse = carve(nullptr, B * NH * (size_t)T); k.ao = carve(nullptr, BT * d); k.x1 = carve(nullptr, BT * d);
         k.ln2 = carve(nullptr, BT * d); k.ln2_mean = carve(nullptr, BT); k.ln2_rstd = carve(nullptr, BT);
         k.cq = carve(nullptr, BT * d); k.ck = carve(nullptr, BK * d); k.cv = carve(nullptr, BK * d);
@@ -172,7 +172,7 @@ void SlateModel::layout_workspace(bool commit) {
     lnf_ = carve("dec_out", BT * d); lnf_mean_ = carve(nullptr, BT); lnf_rstd_ = carve(nullptr, BT);
     pred_ = carve("pred", BT * V);
     gx_ = carve(nullptr, BT * d); gbr_ = carve(nullptr, BT * d); gt1_ = carve(nullptr, BT * d); gt2_ = carve(nullptr, BT * d);
-    gt3_ = carve(nullptr, BT * d); gf1_ = carve(nullptr, BT * 4 * d);
+    gt3_ = carve(nullptr, BT * d); gf1_ = carve(nullptr, BT * 4 * d); gqkv_ = carve(nullptr, BT * 3 * d);
     gmem_ = carve(nullptr, BK * d); gck_ = carve(nullptr, BK * d); gcv_ = carve(nullptr, BK * d);
     gslots_ = carve(nullptr, BK * D); gslots0_ = carve(nullptr, BK * D);
     gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64);
@@ -374,12 +374,11 @@ int SlateModel::fwd_decoder(hipStream_t st) {
         const unsigned site = SITE_BLK_BASE + 8 * b;
         RC(layernorm_fwd_launch(xin, P(pre + "self_attn_layer_norm.weight"), P(pre + "self_attn_layer_norm.bias"), k.ln1, k.ln1_mean, k.ln1_rstd, BT, d, st));
         const float* res = (b == 0) ? k.ln1 : xin;      // block 0 normalises the residual stream itself (transformer.py:175-178)
-        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_q.weight"), nullptr, k.q, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
-        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_k.weight"), nullptr, k.k, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
-        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_v.weight"), nullptr, k.v, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
+        // proj_q / proj_k / proj_v are adjacent in the flat buffer: one [3d, d] weight, one GEMM
+        RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_q.weight"), nullptr, k.q, 3 * d, BT, 3 * d, d, 0, nullptr, 0, 0.f, 0, st));
         {   // causal self attention, flash style (scores never leave the chip)
             AttnArgs a;
-            a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH;
+            a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH; a.ld = 3 * d;
             a.p = p; a.seed = last_.seed; a.site = site + 0;
             RC(attn_launch(a, 0, st));
         }
@@ -480,17 +479,14 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         RC(lin_bwd_x(gb, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt1 = d ao
         {
             AttnArgs a;
-            a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH;
+            a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH; a.ld = 3 * d;
             a.p = p; a.seed = last_.seed; a.site = site + 0;
-            a.dO = gt1_; a.dq = gt2_; a.dk = gt3_; a.dv = gbr_; a.delta = attn_delta_;
+            a.dO = gt1_; a.dq = gqkv_; a.dk = gqkv_ + d; a.dv = gqkv_ + 2 * d; a.delta = attn_delta_;
             RC(attn_launch(a, 1, st));
         }
-        RC(lin_bwd_w(gt2_, d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_w(gt3_, d, k.ln1, d, G(pre + "self_attn.proj_k.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_w(gbr_, d, k.ln1, d, G(pre + "self_attn.proj_v.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_x(gt2_, d, P(pre + "self_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));
-        RC(lin_bwd_x(gt3_, d, P(pre + "self_attn.proj_k.weight"), gt1_, d, BT, d, d, nullptr, 0, gt1_, d, st));
-        RC(lin_bwd_x(gbr_, d, P(pre + "self_attn.proj_v.weight"), gt1_, d, BT, d, d, nullptr, 0, gt1_, d, st));      // gt1 = d ln1
+        // fused [3d, d] weight: dW = [dq|dk|dv]^T ln1 ;  d ln1 = [dq|dk|dv] W
+        RC(lin_bwd_w(gqkv_, 3 * d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, 3 * d, d, 1.f, st));
+        RC(lin_bwd_x(gqkv_, 3 * d, P(pre + "self_attn.proj_q.weight"), gt1_, d, BT, 3 * d, d, nullptr, 0, nullptr, 0, st));      // gt1 = d ln1
         if (b == 0) {
             // ln1 is both the attention input and the residual stream: d ln1_total = gx + gt2, then LN backward to emb
             RC(axpy_launch(gx_, gt1_, BT * d, 1.f, st));

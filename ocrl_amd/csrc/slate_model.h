@@ -117,6 +117,7 @@ private:
     float *attn_delta_;                   // [B,h,T] scratch of the attention backward
     float *lnf_, *lnf_mean_, *lnf_rstd_, *pred_;
     // gradient temporaries
+    float *gqkv_;                         // [BT, 3d] fused dq|dk|dv
     float *gx_, *gbr_, *gt1_, *gt2_, *gt3_, *gf1_, *gmem_, *gck_, *gcv_, *gslots_, *gslots0_;
     float *gA_, *gB_;                     // [B*N,64] (CNN encoder / slot-attention input gradients)
     float *gdA_, *gdB_;                   // dVAE decoder gradient ping-pong (up to [B*4T,256])
