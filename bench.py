@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--obs-size", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1, help="diagnostic only: the headline number uses the reference default 0.1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,6 +86,7 @@ def main():
     from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
     S, B = args.obs_size, args.batch
     ocr, env = slate_config(S)
+    ocr.learning.dropout = args.dropout
     torch.manual_seed(0)                       # identical initial weights on every rank
     model = ocrs.SLATE(ocr, env)
     model._module._max_batch = B

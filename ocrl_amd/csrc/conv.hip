@@ -13,6 +13,7 @@
 //     permuted to the reference [co][ci][ky][kx] layout) by conv_wgrad_reduce_kernel.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define TH 4
 #define TW 32
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
             const int it = tap * NCH + cc;
             const float4 b0 = nb0, b1 = nb1;
             if (it + 1 < NIT) {
-                nb0 = *reinterpret_cast<const float4*>(wl + (size_t)(it + 1) * COUT * 8);
-                nb1 = *reinterpret_cast<const float4*>(wl + (size_t)(it + 1) * COUT * 8 + 32 * 8);
+                const size_t wo = p.diag ? 0 : (size_t)(it + 1) * COUT * 8;
+                nb0 = *reinterpret_cast<const float4*>(wl + wo);
+                nb1 = *reinterpret_cast<const float4*>(wl + wo + 32 * 8);
             }
             const float4 a = *reinterpret_cast<const float4*>(arow + cc * 8);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
@@ -243,7 +245,9 @@ static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-int conv_fwd_launch(const ConvArgs& a, int KS, int CIN, int COUT, hipStream_t st) {
+int conv_fwd_launch(const ConvArgs& a_in, int KS, int CIN, int COUT, hipStream_t st) {
+    ConvArgs a = a_in;
+    { static int dg = -1; if (dg < 0) { const char* e = getenv("OCRL_CONV_DIAG"); dg = e ? atoi(e) : 0; } a.diag = dg; }
     OCRL_REQUIRE(COUT == 64, "conv: COUT must be 64 (got %d)", COUT);
     OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "conv: empty input");
     OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.Wp & 15) == 0, "conv: X/Wp must be 16-byte aligned");

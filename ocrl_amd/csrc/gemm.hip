@@ -28,9 +28,25 @@ struct TileA {
 // global -> registers for one operand tile.  rows = extent along m (or n), base points at
 // element (row 0, k 0) of this block's tile.  rows_valid / k_valid bound the loads; anything
 // outside is zero.
-template <int BMN, bool KC>
+struct ADrop {            // A-operand dropout: element index = lrow * ld + lcol of the logical row-major tensor
+    float p; unsigned site; unsigned long long seed; long long base; int ld;
+};
+__device__ inline float4 adrop_apply(float4 v, const ADrop& d, long long lrow, int lcol) {
+    const uint64_t idx = (uint64_t)(d.base + lrow * d.ld + lcol);
+    const uint2 bits = rng_bits4(d.seed, d.site, idx >> 2);
+    const uint32_t thr = drop_thresh(d.p);
+    const float sc = 1.0f / (1.0f - d.p);
+    v.x = rng_keep(bits, 0, thr) ? v.x * sc : 0.f;
+    v.y = rng_keep(bits, 1, thr) ? v.y * sc : 0.f;
+    v.z = rng_keep(bits, 2, thr) ? v.z * sc : 0.f;
+    v.w = rng_keep(bits, 3, thr) ? v.w * sc : 0.f;
+    return v;
+}
+
+// mn0 / k0: logical coordinates of the tile origin (only used for the dropout index)
+template <int BMN, bool KC, bool DROP>
 __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_valid, int k_valid,
-                                 float4 (&r)[BMN / 32]) {
+                                 float4 (&r)[BMN / 32], const ADrop& dr, int mn0, int k0) {
     const int t = threadIdx.x;
     if (KC) {
         const int c4 = t & 7, r0 = t >> 3;
@@ -38,7 +54,10 @@ __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_v
         for (int i = 0; i < BMN / 32; ++i) {
             const int row = r0 + 32 * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < rows_valid && c4 * 4 < k_valid) v = *reinterpret_cast<const float4*>(g + (size_t)row * ld + c4 * 4);
+            if (row < rows_valid && c4 * 4 < k_valid) {
+                v = *reinterpret_cast<const float4*>(g + (size_t)row * ld + c4 * 4);
+                if (DROP) v = adrop_apply(v, dr, mn0 + row, k0 + c4 * 4);          // logical [m][k]
+            }
             r[i] = v;
         }
     } else {
@@ -49,7 +68,10 @@ __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_v
         for (int i = 0; i < BMN / 32; ++i) {
             const int kr = r0 + RPP * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kr < k_valid && c4 * 4 < rows_valid) v = *reinterpret_cast<const float4*>(g + (size_t)kr * ld + c4 * 4);
+            if (kr < k_valid && c4 * 4 < rows_valid) {
+                v = *reinterpret_cast<const float4*>(g + (size_t)kr * ld + c4 * 4);
+                if (DROP) v = adrop_apply(v, dr, k0 + kr, mn0 + c4 * 4);           // stored [k][m]: logical row = k
+            }
             r[i] = v;
         }
     }
@@ -87,13 +109,13 @@ __device__ inline void load_frag(const float* __restrict__ s, int row0, int c, f
     }
 }
 
-template <int BM, int BN, bool AKC, bool BKC>
+template <int BM, int BN, bool AKC, bool BKC, bool SB, bool ADROP>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int AE = TileA<BM, AKC>::ELEMS, BE = TileA<BN, BKC>::ELEMS;
     float* const As0 = smem;
-    float* const Bs0 = smem + 2 * AE;
+    float* const Bs0 = smem + (SB ? 1 : 2) * AE;
 
     // block -> (tile, z) with an XCD-aware bijective remap of the tile index
     const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
@@ -132,11 +154,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
+    ADrop adr;
+    adr.p = p.adrop_p; adr.site = p.adrop_site; adr.seed = p.drop_seed; adr.ld = p.adrop_ld; adr.base = 0;
+    // fused bias gradient (dW form): column sums of the staged A tile, taken by the first BM threads of the bn == 0 blocks
+    const bool do_bias = !AKC && p.bias_out != nullptr && bn == 0;
+    float bsum = 0.f;
+    auto bias_acc = [&](const float* as) {
+        if (!AKC && do_bias && (int)threadIdx.x < BM) {
+            constexpr int LD = TileA<BM, AKC>::LD;
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) bsum += as[k * LD + threadIdx.x];
+        }
+    };
     float4 ra[BM / 32], rb[BN / 32];
+    if (SB) {
+        // single LDS buffer (half the LDS -> twice the resident workgroups): next tile's global loads fly during compute
+        if (kt0 < kt1) {
+            const int k0 = kt0 * BK;
+            load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
+            load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
+        }
+        for (int kt = kt0; kt < kt1; ++kt) {
+            __syncthreads();
+            store_tile<BM, AKC>(As0, ra);
+            store_tile<BN, BKC>(Bs0, rb);
+            __syncthreads();
+            if (kt + 1 < kt1) {
+                const int k0 = (kt + 1) * BK;
+                load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
+                load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
+            }
+            bias_acc(As0);
+#pragma unroll
+            for (int c = 0; c < BK / 8; ++c) {
+                float fa[TM][4], fb[TN][4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) load_frag<BM, AKC>(As0, wm0 + i * 32, c, fa[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) load_frag<BN, BKC>(Bs0, wn0 + j * 32, c, fb[j]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+            }
+        }
+    } else {
     if (kt0 < kt1) {
         const int k0 = kt0 * BK;
-        load_tile<BM, AKC>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra);
-        load_tile<BN, BKC>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb);
+        load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
+        load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
         store_tile<BM, AKC>(As0, ra);
         store_tile<BN, BKC>(Bs0, rb);
     }
@@ -145,11 +214,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         const int cur = (kt - kt0) & 1;
         if (kt + 1 < kt1) {
             const int k0 = (kt + 1) * BK;
-            load_tile<BM, AKC>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra);
-            load_tile<BN, BKC>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb);
+            load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
+            load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
         }
         const float* as = As0 + cur * AE;
         const float* bs = Bs0 + cur * BE;
+        bias_acc(as);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             float fa[TM][4], fb[TN][4];
@@ -171,9 +241,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
+    }
 
     // ---- epilogue
     const bool partial = p.splitk > 1;
+    if (!AKC && do_bias && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < p.M)
+        p.bias_out[(partial ? (size_t)split * p.sBias : 0) + m0 + threadIdx.x] = bsum;
     float* C = p.C + (size_t)bo * p.sC + (size_t)bi * p.sCi + (partial ? (size_t)split * p.sCsplit : 0);
     const float* R = p.resid ? p.resid + (size_t)batch * p.sR : nullptr;
     const float* Mk = p.mask ? p.mask + (size_t)batch * p.sMask : nullptr;
@@ -230,21 +303,41 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BM, int BN, bool AKC, bool BKC>
-static int launch_cfg(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = (2 * TileA<BM, AKC>::ELEMS + 2 * TileA<BN, BKC>::ELEMS) * 4;
+static int sb_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OCRL_GEMM_SB"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool SB, bool ADROP>
+static int launch_cfg3(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = ((SB ? 1 : 2) * TileA<BM, AKC>::ELEMS + (SB ? 1 : 2) * TileA<BN, BKC>::ELEMS) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, AKC, BKC>,
+        OCRL_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, AKC, BKC, SB, ADROP>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.batch * a.splitk);
     const int pi = prof_begin(PROF_GEMM, st);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, SB, ADROP>), grid, dim3(256), smem, st, a);
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("gemm_kernel");
     return 0;
+}
+template <int BM, int BN, bool AKC, bool BKC, bool SB>
+static int launch_cfg2(const GemmArgs& a, hipStream_t st) {
+    if (a.adrop_p > 0.f) return launch_cfg3<BM, BN, AKC, BKC, SB, true>(a, st);
+    return launch_cfg3<BM, BN, AKC, BKC, SB, false>(a, st);
+}
+template <int BM, int BN, bool AKC, bool BKC>
+static int launch_cfg(const GemmArgs& a, hipStream_t st) {
+    // measured (tools/bench_gemm.py): a single LDS buffer (twice the resident workgroups) wins for the short-K
+    // forward / dX forms (+8..37 %); the long split-K weight-gradient loops keep the double buffer.
+    const int mode = sb_mode();           // OCRL_GEMM_SB: 0 = rule above, 1 = always single, 2 = always double
+    const bool sb = mode == 1 || (mode == 0 && AKC);
+    if (sb) return launch_cfg2<BM, BN, AKC, BKC, true>(a, st);
+    return launch_cfg2<BM, BN, AKC, BKC, false>(a, st);
 }
 
 // development override: OCRL_GEMM_TILE=BMxBN (e.g. 128x64) forces one tile shape
@@ -265,8 +358,6 @@ static int launch_tr(const GemmArgs& a, hipStream_t st) {
         case 128064: return launch_cfg<128, 64, AKC, BKC>(a, st);
         case 64128: return launch_cfg<64, 128, AKC, BKC>(a, st);
         case 64064: return launch_cfg<64, 64, AKC, BKC>(a, st);
-        case 256064: return launch_cfg<256, 64, AKC, BKC>(a, st);
-        case 256128: return launch_cfg<256, 128, AKC, BKC>(a, st);
         default: break;
     }
     // measured on MI355X (tools/bench_gemm.py): 128-wide column tiles only pay when N is a multiple of 128;
@@ -293,6 +384,8 @@ int gemm_launch(const GemmArgs& a_in, hipStream_t st) {
     OCRL_REQUIRE(a.batch_inner >= 1 && a.batch % a.batch_inner == 0, "gemm: batch must be a multiple of batch_inner");
     OCRL_REQUIRE(a.splitk == 1 || a.batch == 1, "gemm: split-k with batches is not supported");
     if (a.splitk > 1) OCRL_REQUIRE(a.sCsplit >= (long long)(a.M - 1) * a.ldc + a.N, "gemm: split-k slab stride too small");
+    if (a.adrop_p > 0.f) OCRL_REQUIRE(a.adrop_ld > 0 && a.adrop_ld % 4 == 0 && a.batch == 1, "gemm: A-dropout needs adrop_ld %% 4 == 0 and no batching");
+    if (a.bias_out) OCRL_REQUIRE(!a.akc && (a.splitk == 1 || a.sBias >= a.M), "gemm: fused bias gradient needs the dW form");
     if (a.akc && a.bkc) return launch_tr<true, true>(a, st);
     if (a.akc && !a.bkc) return launch_tr<true, false>(a, st);
     if (!a.akc && !a.bkc) return launch_tr<false, false>(a, st);

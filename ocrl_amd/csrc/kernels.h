@@ -31,6 +31,11 @@ struct GemmArgs {
     unsigned drop_site = 0;
     const float* mask = nullptr; int ldmask = 0; long long sMask = 0;
     const float* resid = nullptr; int ldr = 0; long long sR = 0;
+    // A-operand dropout (backward of y = x + dropout(branch)): A element (m, n) of the logical row-major [rows, adrop_ld]
+    // tensor is multiplied by keep/(1-p) of dropout site adrop_site while it is staged (no separate mask pass)
+    float adrop_p = 0.f; unsigned adrop_site = 0; int adrop_ld = 0;
+    // fused bias gradient for the dW form (akc == 0): bias_out[m] = sum_k A(m,k)  (partials per split at stride sBias)
+    float* bias_out = nullptr; long long sBias = 0;
 };
 int gemm_launch(const GemmArgs& a, hipStream_t st);
 int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
@@ -46,6 +51,7 @@ struct ConvArgs {
     int relu = 0;
     const float* posmap = nullptr;  // [H,W,COUT] added after bias/relu
     const float* mask = nullptr;    // [B,H,W,COUT]: output zeroed where mask <= 0 (ReLU backward)
+    int diag = 0;                   // development diagnostic (OCRL_CONV_DIAG): wrong results, timing only
 };
 struct WgradArgs {
     const float* X = nullptr;       // [B,H,W,CIN]

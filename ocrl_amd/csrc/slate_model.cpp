@@ -250,34 +250,43 @@ int SlateModel::lin_fwd(const float* x, int ldx, const float* W, const float* b,
     a.bias = b; a.relu = relu; a.resid = resid; a.ldr = ldr; a.drop_p = drop_p; a.drop_seed = last_.seed; a.drop_site = site;
     return gemm_launch(a, st);
 }
-// dx[M,K_in] = (dy[M,N_out] W[N_out,K_in]) * (mask > 0) + resid
+// dx[M,K_in] = (drop(dy)[M,N_out] W[N_out,K_in]) * (mask > 0) + resid
 int SlateModel::lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx, int ldx, long long M, int N_out, int K_in,
-                          const float* mask, int ldmask, const float* resid, int ldr, hipStream_t st) {
+                          const float* mask, int ldmask, const float* resid, int ldr, hipStream_t st, Drop dr) {
     GemmArgs a;
     a.A = dy; a.B = W; a.C = dx; a.M = (int)M; a.N = K_in; a.K = N_out; a.lda = ld_dy; a.ldb = K_in; a.ldc = ldx; a.akc = 1; a.bkc = 0;
     a.mask = mask; a.ldmask = ldmask; a.resid = resid; a.ldr = ldr;
+    if (dr.p > 0.f) { a.adrop_p = dr.p; a.adrop_site = dr.site; a.adrop_ld = N_out; a.drop_seed = last_.seed; }
     return gemm_launch(a, st);
 }
-// dW[N_out,K_in] = alpha * dy^T x (split over the M rows);  db[N_out] = column sums of dy
+// dW[N_out,K_in] = alpha * drop(dy)^T x (split over the M rows);  db[N_out] = column sums of drop(dy), fused into the GEMM
 int SlateModel::lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in,
-                          float alpha, hipStream_t st) {
+                          float alpha, hipStream_t st, Drop dr) {
     GemmArgs a;
     a.A = dy; a.B = x; a.C = dW; a.M = N_out; a.N = K_in; a.K = (int)M; a.lda = ld_dy; a.ldb = ldx; a.ldc = K_in; a.akc = 0; a.bkc = 0;
     a.alpha = alpha;
-    const int tiles = cdiv(N_out, 128) * cdiv(K_in, K_in > 64 ? 128 : 64);
+    if (dr.p > 0.f) { a.adrop_p = dr.p; a.adrop_site = dr.site; a.adrop_ld = N_out; a.drop_seed = last_.seed; }
+    const int tiles = cdiv(N_out, 128) * cdiv(K_in, (K_in % 128 == 0) ? 128 : 64);
     long long splits = 1024 / tiles;
     if (splits > M / 256) splits = M / 256;
     if (splits < 1) splits = 1;
     const long long slab = (long long)N_out * K_in;
-    if (splits * slab > (long long)scratch_floats_) splits = (long long)scratch_floats_ / slab;
+    const long long bslab = (N_out + 3) & ~3;
+    if (splits * (slab + bslab) > (long long)scratch_floats_) splits = (long long)scratch_floats_ / (slab + bslab);
     if (splits > 1) {
         a.splitk = (int)splits; a.C = scratch_; a.sCsplit = slab;
+        float* bpart = scratch_ + splits * slab;
+        if (db) { a.bias_out = bpart; a.sBias = bslab; }
         RC(gemm_launch(a, st));
         RC(splitk_reduce_launch(scratch_, dW, slab, (int)splits, slab, 0, st));
+        if (db) {
+            if (N_out % 4 == 0) RC(splitk_reduce_launch(bpart, db, N_out, (int)splits, bslab, 0, st));
+            else RC(colsum_launch(bpart, bslab, db, splits, N_out, 0, 1.f, bpart + splits * bslab, scratch_floats_ - (size_t)(splits * (slab + bslab)), st));
+        }
     } else {
+        if (db) a.bias_out = db;
         RC(gemm_launch(a, st));
     }
-    if (db) RC(colsum_launch(dy, ld_dy, db, M, N_out, 0, 1.f, scratch_, scratch_floats_, st));
     return 0;
 }
 int SlateModel::conv_layer_fwd(const float* x, const float* pack, const float* bias, float* y, int Bn, int Hh, int Ww, int KS, int CIN,
@@ -448,19 +457,18 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         const unsigned site = SITE_BLK_BASE + 8 * b;
         const float* xin = (b == 0) ? emb_ : blk_[b - 1].x3;
         // ---- feed forward:  x3 = x2 + drop(W2 relu(W1 ln3 + b1) + b2)
-        const float* gb = gx_;
-        if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 4, st)); gb = gbr_; }
-        RC(lin_bwd_w(gb, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d, 1.f, st));
-        RC(lin_bwd_x(gb, d, P(pre + "ffn.2.weight"), gf1_, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st));
+        Drop dr;
+        dr.p = p; dr.site = site + 4;
+        RC(lin_bwd_w(gx_, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d, 1.f, st, dr));
+        RC(lin_bwd_x(gx_, d, P(pre + "ffn.2.weight"), gf1_, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st, dr));
         RC(lin_bwd_w(gf1_, 4 * d, k.ln3, d, G(pre + "ffn.0.weight"), G(pre + "ffn.0.bias"), BT, 4 * d, d, 1.f, st));
         RC(lin_bwd_x(gf1_, 4 * d, P(pre + "ffn.0.weight"), gt1_, d, BT, 4 * d, d, nullptr, 0, nullptr, 0, st));
         RC(layernorm_bwd_launch(gt1_, k.x2, k.ln3_mean, k.ln3_rstd, P(pre + "ffn_layer_norm.weight"), gx_, G(pre + "ffn_layer_norm.weight"), BT, d, 1, 0,
                                 scratch_, scratch_floats_, st));
         // ---- cross attention
-        gb = gx_;
-        if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 3, st)); gb = gbr_; }
-        RC(lin_bwd_w(gb, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_x(gb, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d cao
+        dr.site = site + 3;
+        RC(lin_bwd_w(gx_, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st, dr));
+        RC(lin_bwd_x(gx_, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st, dr));   // d cao
         RC(fill_launch(gck_, BK * d, 0.f, st));
         RC(fill_launch(gcv_, BK * d, 0.f, st));
         RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, gt2_, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, st));   // gt2 = d cq
@@ -473,10 +481,9 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         RC(layernorm_bwd_launch(gt1_, k.x1, k.ln2_mean, k.ln2_rstd, P(pre + "encoder_decoder_attn_layer_norm.weight"), gx_,
                                 G(pre + "encoder_decoder_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         // ---- causal self attention
-        gb = gx_;
-        if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, site + 1, st)); gb = gbr_; }
-        RC(lin_bwd_w(gb, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_x(gb, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt1 = d ao
+        dr.site = site + 1;
+        RC(lin_bwd_w(gx_, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st, dr));
+        RC(lin_bwd_x(gx_, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st, dr));   // gt1 = d ao
         {
             AttnArgs a;
             a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH; a.ld = 3 * d;

@@ -35,6 +35,9 @@ struct StepInputs {
     const float* noise_slots = nullptr;  // optional injected N(0,1) [B,K,D]
 };
 
+// dropout-backward mask applied to dy while the GEMM stages it
+struct Drop { float p = 0.f; unsigned site = 0; };
+
 class SlateModel {
 public:
     explicit SlateModel(const SlateConfig& c);
@@ -61,9 +64,9 @@ private:
     int lin_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, long long M, int N, int K, int relu,
                 const float* resid, int ldr, float drop_p, unsigned site, hipStream_t st);
     int lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx, int ldx, long long M, int N_out, int K_in, const float* mask,
-                  int ldmask, const float* resid, int ldr, hipStream_t st);
+                  int ldmask, const float* resid, int ldr, hipStream_t st, Drop dr = Drop());
     int lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in,
-                  float alpha, hipStream_t st);
+                  float alpha, hipStream_t st, Drop dr = Drop());
     int conv_layer_fwd(const float* x, const float* pack, const float* bias, float* y, int Bn, int Hh, int Ww, int KS, int CIN, int relu,
                        const float* posmap, const float* mask, hipStream_t st);
     int conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN, int cin_real,
