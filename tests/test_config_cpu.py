@@ -1,0 +1,103 @@
+"""Host logic on CPU: the Hydra-grammar resolver, the synthetic dataset, ARI, schedules, the API surface."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ocrl_amd.utils.config import compose
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs")
+
+
+def test_compose_reference_command_line():
+    c = compose(CFG, "train_ocr", ["ocr=slate", "ocr.slotattr.num_slots=6", "ocr.slotattr.num_iterations=3",
+                                   "dataset=random-N5C4S4S2", "device=cuda:0", "tags=slate", "dataset.obs_size=128", "batch_size=4"])
+    assert c.ocr.name == "SLATE" and c.ocr.slotattr.num_slots == 6 and c.ocr.dvae.vocab_size == 4096
+    assert c.ocr.learning.clip == 0.05 and c.ocr.learning.lr_dvae == pytest.approx(3e-4)
+    assert c.dataset.obs_size == 128 and c.dataset.obs_channels == 3 and c.dataset.name == "RandomN5C4S4S2"
+    assert c.batch_size == 4 and c.eval_interval == 1000 and c.max_epochs == 1000 and c.seed == 0
+    assert c.run_dir.endswith("SLATE-RandomN5C4S4S2")
+    # DictConfig-style probes used by the reference (ocrs/base.py:21-22,65-66)
+    assert hasattr(c.ocr, "learning") and not hasattr(c.ocr.learning, "lr") and hasattr(c.ocr.learning, "clip")
+    assert c.dataset.dataset_dir == "datasets"          # inherited through _synthetic_env_base -> _base
+
+
+def test_mandatory_groups_and_bad_overrides():
+    with pytest.raises(ValueError, match="You must specify 'ocr'"):
+        compose(CFG, "train_ocr", ["dataset=random-N5C4S4S2"])
+    with pytest.raises(KeyError):
+        compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2", "ocr.nonexistent=1"])
+    c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2", "+ocr.extra=7"])
+    assert c.ocr.extra == 7
+    with pytest.raises(FileNotFoundError):
+        compose(CFG, "train_ocr", ["ocr=nope", "dataset=random-N5C4S4S2"])
+
+
+def test_slotattn_alias_config():
+    c = compose(CFG, "train_ocr", ["ocr=slotattn", "dataset=random-N5C4S4S2"])
+    assert c.ocr.name == "SLATE" and c.ocr.use_bcdec is True and c.ocr.slotattr.slot_size == 192
+
+
+def test_synthetic_scenes_follow_the_env_spec():
+    from ocrl_amd.utils.data import random_sprite_scenes
+    img, masks = random_sprite_scenes(6, 64, seed=3, with_masks=True)
+    assert img.shape == (6, 64, 64, 3) and img.dtype == np.uint8
+    assert masks.shape == (6, 6, 64, 64, 1)
+    assert np.allclose(masks.sum(1), 1.0)                              # a partition: objects + background
+    assert np.array_equal(img, random_sprite_scenes(6, 64, seed=3))    # deterministic
+    colours = {tuple(c) for c in img.reshape(-1, 3)}
+    assert colours <= {(0, 0, 0), (0, 0, 255), (0, 255, 0), (255, 255, 0), (255, 0, 0)}
+    assert (masks[:, -1].mean() > 0.5)                                 # mostly background
+
+
+def test_dataset_and_loader_sample_format():
+    from ocrl_amd.utils.datasets import get_dataloaders
+    c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2", "dataset.synthetic_train=16", "dataset.synthetic_val=8",
+                                   "dataset.with_masks=True"])
+    tr, va = get_dataloaders(c.dataset, 4, 0)
+    b = next(iter(tr))
+    assert b["obss"].shape == (4, 3, 64, 64) and b["obss"].dtype == torch.float32 and 0 <= b["obss"].min() and b["obss"].max() <= 1
+    assert b["masks"].permute(0, 1, 4, 2, 3).shape == (4, 6, 1, 64, 64)
+    assert len(va.dataset) == 8
+
+
+def test_ari_matches_sklearn():
+    from sklearn.metrics import adjusted_rand_score
+    from ocrl_amd.utils.tools import _adjusted_rand_score
+    rs = np.random.RandomState(0)
+    for _ in range(5):
+        a, b = rs.randint(0, 5, 500), rs.randint(0, 4, 500)
+        assert _adjusted_rand_score(a, b) == pytest.approx(adjusted_rand_score(a, b), abs=1e-12)
+    assert _adjusted_rand_score([0, 0, 1, 1], [1, 1, 0, 0]) == pytest.approx(1.0)
+
+
+def test_slate_surface_matches_reference_names():
+    from oracle import slate_oracle as O
+    from ocrl_amd import ocrs
+    c = compose(CFG, "train_ocr", ["ocr=slate", "ocr.slotattr.num_slots=6", "dataset=random-N5C4S4S2"])
+    m = ocrs.SLATE(c.ocr, c.dataset)
+    assert m.name == "SLATE" and m.rep_dim == 192 and m.num_slots == 6
+    sd = m._module.state_dict()
+    cfg = O.default_cfg(obs_size=64, num_slots=6)
+    assert {k for k in sd if not k.endswith("linear_position_embedding")} == {n for n, _, _, _ in O.param_shapes(cfg)}
+    for n, shp, _, _ in O.param_shapes(cfg):
+        assert tuple(sd[n].shape) == tuple(shp), n
+    names = {id(p): n for n, p in m._module.named_parameters()}
+    for g in range(3):
+        assert [names[id(p)] for p in m._opt.param_groups[g]["params"]] == [n for n, _, gg, _ in O.param_shapes(cfg) if gg == g]
+    ck = m.save()
+    assert set(ck) == {"ocr_module_state_dict", "ocr_opt_state_dict"} and set(ck["ocr_opt_state_dict"]) == {"state", "param_groups"}
+    with pytest.raises(RuntimeError):
+        m.to("cpu")
+    with pytest.raises(NotImplementedError):
+        ocrs.SLATE(compose(CFG, "train_ocr", ["ocr=slotattn", "dataset=random-N5C4S4S2"]).ocr, c.dataset)
+
+
+def test_schedules_match_oracle():
+    from oracle import slate_oracle as O
+    from ocrl_amd.ocrs.slate import cosine_anneal, linear_warmup
+    for step in (0, 1, 999, 15000, 29999, 30000, 50000):
+        assert cosine_anneal(step, 1.0, 0.1, 0, 30000) == O.cosine_anneal(step, 1.0, 0.1, 0, 30000)
+        assert linear_warmup(step, 0, 1, 0, 30000) == O.linear_warmup(step, 0, 1, 0, 30000)
