@@ -101,6 +101,16 @@ int ocrl_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int ocrl_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx, float* dgb,
                        long long R, int F, float* ws, size_t ws_floats, void* stream);
 
+/* Causal multi-head self-attention core of MultiHeadAttention.forward (ocrs/common/transformer.py:31-47): q,k,v are the
+ * projected [B,T,d] tensors (row stride ld >= d, heads side by side, q unscaled); o = dropout(softmax(mask(q k^T / sqrt(dh)))) v
+ * as [B,T,d]; lse [B,h,T] is saved for the backward.  Dropout decisions come from (seed, site) as in ocrl_slate_forward. */
+int ocrl_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int d, int h, int ld,
+                       float p, unsigned long long seed, unsigned site, void* stream);
+/* gradients dq,dk,dv (row stride ld) from dO [B,T,d]; delta is scratch [B,h,T]. */
+int ocrl_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* dO,
+                       float* dq, float* dk, float* dv, float* delta, int B, int T, int d, int h, int ld,
+                       float p, unsigned long long seed, unsigned site, void* stream);
+
 /* ---- optional HIP-event timing of kernel families on the launch stream (bench.py's roofline line).
  * tag bits: 0 conv5x5/64ch fwd+bwd-data, 1 other convs, 2 conv weight-grad, 3 gemm, 4 slot-attn fwd, 5 slot-attn bwd,
  * 6 self-attention fwd, 7 self-attention bwd.

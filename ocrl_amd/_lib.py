@@ -57,6 +57,8 @@ def lib():
     L.ocrl_conv2d_bwd_weight.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
     L.ocrl_layernorm_fwd.argtypes = [p, p, p, p, p, p, c_longlong, c_int, p]
     L.ocrl_layernorm_bwd.argtypes = [p, p, p, p, p, p, p, c_longlong, c_int, p, c_size_t, p]
+    L.ocrl_attention_fwd.argtypes = [p, p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_uint, p]
+    L.ocrl_attention_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_uint, p]
     L.ocrl_prof_enable.argtypes = [c_uint]
     L.ocrl_prof_collect.argtypes = [POINTER(ctypes.c_double * 8), POINTER(c_longlong * 8), c_int]
     if L.ocrl_abi_version() != 1:

@@ -144,4 +144,19 @@ int ocrl_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     return layernorm_bwd_launch(dy, x, mean, rstd, g, dx, dgb, R, F, 0, 0, ws, ws_floats, ST(stream));
 }
 
+int ocrl_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int T, int d, int h, int ld, float p,
+                       unsigned long long seed, unsigned site, void* stream) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.B = B; a.T = T; a.d = d; a.h = h; a.ld = ld; a.p = p; a.seed = seed; a.site = site;
+    return attn_launch(a, 0, ST(stream));
+}
+int ocrl_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* dO, float* dq,
+                       float* dk, float* dv, float* delta, int B, int T, int d, int h, int ld, float p, unsigned long long seed,
+                       unsigned site, void* stream) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = const_cast<float*>(o); a.lse = const_cast<float*>(lse); a.B = B; a.T = T; a.d = d; a.h = h; a.ld = ld;
+    a.p = p; a.seed = seed; a.site = site; a.dO = dO; a.dq = dq; a.dk = dk; a.dv = dv; a.delta = delta;
+    return attn_launch(a, 1, ST(stream));
+}
+
 }  // extern "C"
