@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define OCRL_ABI_VERSION 1
+#define OCRL_ABI_VERSION 2
 
 const char* ocrl_last_error(void);
 int ocrl_abi_version(void);
@@ -32,6 +32,7 @@ typedef struct ocrl_slate_config {
     int num_dec_blocks, num_dec_heads;          /* ocr_config.tfdec.* */
     float dropout;                              /* ocr_config.learning.dropout */
     int max_batch;                              /* workspace is sized for this many images */
+    int use_bcdec;                              /* ocr_config.use_bcdec: Slot-Attention configuration (broadcast decoder) */
 } ocrl_slate_config;
 
 int ocrl_slate_create(const ocrl_slate_config* cfg, ocrl_slate** out);

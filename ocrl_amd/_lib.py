@@ -11,7 +11,7 @@ _lib = None
 class SlateConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("obs_size", "obs_channels", "vocab_size", "d_model", "cnn_hidden", "num_slots",
                                       "num_iterations", "slot_size", "mlp_hidden", "num_dec_blocks", "num_dec_heads")] + \
-               [("dropout", c_float), ("max_batch", c_int)]
+               [("dropout", c_float), ("max_batch", c_int), ("use_bcdec", c_int)]
 
 
 def lib():
@@ -61,7 +61,7 @@ def lib():
     L.ocrl_attention_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_uint, p]
     L.ocrl_prof_enable.argtypes = [c_uint]
     L.ocrl_prof_collect.argtypes = [POINTER(ctypes.c_double * 8), POINTER(c_longlong * 8), c_int]
-    if L.ocrl_abi_version() != 1:
+    if L.ocrl_abi_version() != 2:
         raise RuntimeError("libocrl_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -173,3 +173,20 @@ struct AttnArgs {
     float *dq = nullptr, *dk = nullptr, *dv = nullptr, *delta = nullptr;
 };
 int attn_launch(const AttnArgs& a, int mode, hipStream_t st);
+
+// ------------------------------------------------------------------ bcdec.hip (Slot-Attention broadcast decoder)
+int bc_compose_launch(const float* W1, const float* Wpos, const float* bpos, float* Wc, float* W1r, int D, hipStream_t st);
+int bc_posconv_launch(const float* Wc, float* P1, int S, hipStream_t st);
+int bc_class_sum_launch(const float* in, float* out, int BK, int forward, hipStream_t st);
+int bc_layer1_launch(const float* P1, const float* Tc, const float* b1, float* c1, int BK, int S, hipStream_t st);
+int bc_layer1_bwd_launch(const float* g, float* dT, int BK, int S, hipStream_t st);
+int bc_posconv_bwd_launch(const float* G, float* dWc, int S, hipStream_t st);
+int bc_compose_bwd_launch(const float* W1, const float* Wpos, const float* bpos, const float* dWc, const float* dW1r, float* dW1,
+                          float* dWpos, float* dbpos, int D, hipStream_t st);
+int bc_c4_pack_launch(const float* W, float* Wk, float* Wb, int co_n, hipStream_t st);
+int bc_c4_fwd_launch(const float* X, const float* Wk, const float* bias4, float* Y, int Bn, int S, hipStream_t st);
+int bc_c4_bwd_data_launch(const float* dY, const float* Wb, const float* act, float* dX, int Bn, int S, hipStream_t st);
+int bc_c4_wgrad_blocks(int Bn, int S);
+int bc_c4_wgrad_launch(const float* X, const float* dY, float* part, int Bn, int S, hipStream_t st);
+int bc_mix_launch(const float* out4, const float* obs, float* recon, float* dout4, float* loss_out, int B, int K, int S, int C, float* ws,
+                  size_t ws_floats, hipStream_t st);

@@ -65,6 +65,12 @@ SlateModel::SlateModel(const SlateConfig& c) : cfg(c) {
     add(sa + "mlp.0.weight", {H, D}, 1); add(sa + "mlp.0.bias", {H}, 1);
     add(sa + "mlp.2.weight", {D, H}, 1); add(sa + "mlp.2.bias", {D}, 1);
     add("_slotproj.weight", {d, D}, 1);
+    if (c.use_bcdec) {      // ocrs/common/models.py:110-126, appended to the slot-attention group (slate_module.py:96-103)
+        add("_dec._decoder.0.m.weight", {C, D, 5, 5}, 1); add("_dec._decoder.0.m.bias", {C}, 1);
+        for (int i = 1; i < 3; ++i) { add(fmt("_dec._decoder.%d.m.weight", i), {C, C, 5, 5}, 1); add(fmt("_dec._decoder.%d.m.bias", i), {C}, 1); }
+        add("_dec._decoder.3.weight", {ch + 1, C, 3, 3}, 1); add("_dec._decoder.3.bias", {ch + 1}, 1);
+        add("_dec._pos_emb.channels_map.weight", {D, 4, 1, 1}, 1); add("_dec._pos_emb.channels_map.bias", {D}, 1);
+    }
     // group 2
     add("_dict.dictionary.weight", {V, d}, 2);
     add("_bos_token._bos_token", {1, 1, d}, 2);
@@ -116,7 +122,7 @@ void SlateModel::layout_workspace(bool commit) {
     // transient scratch: split-k slabs (<= 1024 slabs of the largest weight tile set), wgrad slabs, column sums
     scratch_floats_ = 0;
     {
-        size_t need = conv_wgrad_ws_floats((int)B, S, S, 5, 64);
+        size_t need = conv_wgrad_ws_floats((int)(B * (cfg.use_bcdec ? K : 1)), S, S, 5, 64) + (size_t)512 * 2304 * 2;
         size_t sk = (size_t)16 * V * d + (size_t)(1 << 20);        // split-k slabs for the [V,d] weights
         if (sk > need) need = sk;
         size_t cs = (size_t)N * C * 8 + (size_t)T * d * 8 + (1 << 20);   // column-sum partials (pos map / pe)
@@ -125,16 +131,6 @@ void SlateModel::layout_workspace(bool commit) {
     }
     scratch_ = carve(nullptr, scratch_floats_);
     obs8_ = carve("obs8", BN * 8);
-    patches_ = carve("patches", BT * 16 * cfg.obs_channels);
-    for (int i = 0; i < 7; ++i) de_[i] = carve(nullptr, BT * 64);
-    zraw_ = carve("zraw", BT * V);
-    z_ = carve("z", BT * V);
-    tokens_ = reinterpret_cast<int*>(carve("tokens", BT));
-    dd0_ = carve(nullptr, BT * 64); dd1_ = carve(nullptr, BT * 64); dd2_ = carve(nullptr, BT * 64); dd3_ = carve(nullptr, BT * 64);
-    dd4_ = carve(nullptr, BT * 256); ps1_ = carve(nullptr, BT * 256);
-    dd6_ = carve(nullptr, BT * 256); dd7_ = carve(nullptr, BT * 256); dd8_ = carve(nullptr, BT * 256);
-    dd9_ = carve(nullptr, BT * 1024); ps2_ = carve(nullptr, BN * 64);
-    recon_ = carve("recon", BN * 4); drecon_ = carve(nullptr, BN * 4);
     e1_ = carve(nullptr, BN * 64); e2_ = carve(nullptr, BN * 64); e3_ = carve(nullptr, BN * 64); e4_ = carve("feats", BN * 64);
     posmap_ = carve(nullptr, (size_t)N * C); gridT_ = carve(nullptr, (size_t)N * 4);
     ln0_ = carve(nullptr, BN * 64); ln0_mean_ = carve(nullptr, BN); ln0_rstd_ = carve(nullptr, BN);
@@ -154,6 +150,32 @@ void SlateModel::layout_workspace(bool commit) {
         cw_fwd_[i] = carve(nullptr, (size_t)25 * cin * 64);
         cw_bwd_[i] = i == 0 ? nullptr : carve(nullptr, (size_t)25 * 64 * 64);
     }
+    gslots_ = carve(nullptr, BK * D); gslots0_ = carve(nullptr, BK * D);
+    gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64);
+    gmap_ = carve(nullptr, (size_t)N * C);
+    if (cfg.use_bcdec) {
+        const size_t BKN = BK * (size_t)N;
+        bc_Wc_ = carve(nullptr, 25 * 64 * 5 + 64); bc_W1r_ = carve(nullptr, (size_t)25 * 64 * D); bc_P1_ = carve(nullptr, (size_t)N * 64);
+        bc_M_ = carve(nullptr, BK * 1600); bc_T_ = carve(nullptr, BK * 1600);
+        bc_c1_ = carve(nullptr, BKN * 64); bc_c2_ = carve(nullptr, BKN * 64); bc_c3_ = carve(nullptr, BKN * 64);
+        bc_out4_ = carve(nullptr, BKN * 4); bc_dout4_ = carve(nullptr, BKN * 4);
+        bc_gA_ = carve(nullptr, BKN * 64); bc_gB_ = carve(nullptr, BKN * 64);
+        for (int i = 0; i < 2; ++i) { bc_pk_[i] = carve(nullptr, 25 * 64 * 64); bc_pkb_[i] = carve(nullptr, 25 * 64 * 64); }
+        bc_Wk4_ = carve(nullptr, 9 * 64 * 4); bc_Wb4_ = carve(nullptr, 9 * 64 * 4);
+        bc_dW1r_ = carve(nullptr, (size_t)25 * 64 * D); bc_dWc_ = carve(nullptr, 25 * 64 * 5 + 64);
+        bc_dT_ = carve(nullptr, BK * 1600); bc_dM_ = carve(nullptr, BK * 1600); bc_G1_ = carve(nullptr, (size_t)N * 64);
+        recon_ = carve("recon", BN * 4);
+    } else {
+    patches_ = carve("patches", BT * 16 * cfg.obs_channels);
+    for (int i = 0; i < 7; ++i) de_[i] = carve(nullptr, BT * 64);
+    zraw_ = carve("zraw", BT * V);
+    z_ = carve("z", BT * V);
+    tokens_ = reinterpret_cast<int*>(carve("tokens", BT));
+    dd0_ = carve(nullptr, BT * 64); dd1_ = carve(nullptr, BT * 64); dd2_ = carve(nullptr, BT * 64); dd3_ = carve(nullptr, BT * 64);
+    dd4_ = carve(nullptr, BT * 256); ps1_ = carve(nullptr, BT * 256);
+    dd6_ = carve(nullptr, BT * 256); dd7_ = carve(nullptr, BT * 256); dd8_ = carve(nullptr, BT * 256);
+    dd9_ = carve(nullptr, BT * 1024); ps2_ = carve(nullptr, BN * 64);
+    recon_ = carve("recon", BN * 4); drecon_ = carve(nullptr, BN * 4);
     for (int i = 0; i < 2; ++i) { dw_fwd_[i] = carve(nullptr, 9 * 64 * 64); dw_bwd_[i] = carve(nullptr, 9 * 64 * 64); }
     w11p_ = carve(nullptr, 4 * 64);
     mem_ = carve("mem", BK * d); emb_ = carve("emb", BT * d);
@@ -174,10 +196,8 @@ void SlateModel::layout_workspace(bool commit) {
     gx_ = carve(nullptr, BT * d); gbr_ = carve(nullptr, BT * d); gt1_ = carve(nullptr, BT * d); gt2_ = carve(nullptr, BT * d);
     gt3_ = carve(nullptr, BT * d); gf1_ = carve(nullptr, BT * 4 * d); gqkv_ = carve(nullptr, BT * 3 * d);
     gmem_ = carve(nullptr, BK * d); gck_ = carve(nullptr, BK * d); gcv_ = carve(nullptr, BK * d);
-    gslots_ = carve(nullptr, BK * D); gslots0_ = carve(nullptr, BK * D);
-    gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64);
     gdA_ = carve(nullptr, BN * 64); gdB_ = carve(nullptr, BN * 64);
-    gmap_ = carve(nullptr, (size_t)N * C);
+    }
     if (!commit) ws_bytes_ = ws_off_ + 4096;
 }
 
@@ -310,10 +330,12 @@ int SlateModel::pack_weights(hipStream_t st) {
     RC(conv_pack_launch(P("_enc._encoder.1.m.weight"), cw_fwd_[1], cw_bwd_[1], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_enc._encoder.2.m.weight"), cw_fwd_[2], cw_bwd_[2], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_enc._encoder.3.weight"), cw_fwd_[3], cw_bwd_[3], 5, 64, 64, 64, st));
-    RC(conv_pack_launch(P("_dvae._decoder.1.m.weight"), dw_fwd_[0], dw_bwd_[0], 3, 64, 64, 64, st));
-    RC(conv_pack_launch(P("_dvae._decoder.6.m.weight"), dw_fwd_[1], dw_bwd_[1], 3, 64, 64, 64, st));
-    RC(copy_launch(P("_dvae._decoder.11.weight"), w11p_, cfg.obs_channels * 64, st));    // [3,64] -> [4,64], row 3 zero
-    RC(fill_launch(w11p_ + cfg.obs_channels * 64, (4 - cfg.obs_channels) * 64, 0.f, st));
+    if (!cfg.use_bcdec) {
+        RC(conv_pack_launch(P("_dvae._decoder.1.m.weight"), dw_fwd_[0], dw_bwd_[0], 3, 64, 64, 64, st));
+        RC(conv_pack_launch(P("_dvae._decoder.6.m.weight"), dw_fwd_[1], dw_bwd_[1], 3, 64, 64, 64, st));
+        RC(copy_launch(P("_dvae._decoder.11.weight"), w11p_, cfg.obs_channels * 64, st));    // [3,64] -> [4,64], row 3 zero
+        RC(fill_launch(w11p_ + cfg.obs_channels * 64, (4 - cfg.obs_channels) * 64, 0.f, st));
+    }
     RC(pack_launch(sa_pack_dev_, sa_pack_n_, sa_pack_max_, sa_wts_, st));
     RC(posmap_launch(P("_enc_pos.channels_map.weight"), P("_enc_pos.channels_map.bias"), posmap_, S, C, st));
     return 0;
@@ -418,6 +440,15 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
     last_ = in;
     pdrop_ = in.train ? cfg.dropout : 0.f;
     RC(pack_weights(st));
+    if (cfg.use_bcdec) {      // slate_module.py:218-225: loss = mse of the broadcast-decoder reconstruction
+        RC(fwd_encoder(in, st));
+        RC(pack_bcdec(st));
+        RC(fwd_bcdec(st));
+        RC(fill_launch(metrics_ + 1, 1, 0.f, st));
+        RC(copy_launch(metrics_ + 0, metrics_ + 2, 1, st));
+        have_fwd_ = true;
+        return 0;
+    }
     RC(fwd_dvae(in, st));
     RC(fwd_encoder(in, st));
     RC(fwd_decoder(st));
@@ -620,6 +651,13 @@ int SlateModel::bwd_dvae(hipStream_t st) {
 int SlateModel::backward(hipStream_t st) {
     OCRL_REQUIRE(have_fwd_, "backward: call forward first");
     OCRL_REQUIRE(g_, "backward: no gradient buffer bound");
+    if (cfg.use_bcdec) {
+        RC(fill_launch(g_, flat_size_, 0.f, st));       // dVAE / transformer / slotproj parameters get no gradient in this mode
+        RC(bwd_bcdec(st));
+        RC(bwd_encoder(st));
+        have_fwd_ = false;
+        return 0;
+    }
     RC(bwd_decoder(st));
     RC(bwd_encoder(st));
     RC(bwd_dvae(st));
@@ -635,8 +673,60 @@ int SlateModel::clip_adam(const float lr[3], float clip, int step, float gscale,
     OCRL_REQUIRE(m_ && v_, "clip_adam: optimiser state not bound");
     RC(grad_norm(st));
     for (int g = 0; g < 3; ++g) {
+        if (cfg.use_bcdec && g != 1) continue;      // parameters without gradients are skipped, as torch's Adam does
         const long long b0 = group_begin_[g], n = group_begin_[g + 1] - b0;
         RC(clip_adam_launch(p_ + b0, g_ + b0, m_ + b0, v_ + b0, n, metrics_ + 3, clip, lr[g], 0.9f, 0.999f, 1e-8f, step, gscale, st));
     }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slot-Attention configuration: spatial-broadcast decoder (ocrs/common/models.py:110-141)
+int SlateModel::pack_bcdec(hipStream_t st) {
+    RC(bc_compose_launch(P("_dec._decoder.0.m.weight"), P("_dec._pos_emb.channels_map.weight"), P("_dec._pos_emb.channels_map.bias"), bc_Wc_,
+                         bc_W1r_, D, st));
+    RC(conv_pack_launch(P("_dec._decoder.1.m.weight"), bc_pk_[0], bc_pkb_[0], 5, 64, 64, 64, st));
+    RC(conv_pack_launch(P("_dec._decoder.2.m.weight"), bc_pk_[1], bc_pkb_[1], 5, 64, 64, 64, st));
+    RC(bc_c4_pack_launch(P("_dec._decoder.3.weight"), bc_Wk4_, bc_Wb4_, cfg.obs_channels + 1, st));
+    return 0;
+}
+
+int SlateModel::fwd_bcdec(hipStream_t st) {
+    const int B = last_.B, BK = B * K;
+    RC(bc_posconv_launch(bc_Wc_, bc_P1_, S, st));
+    RC(lin_fwd(slots_, D, bc_W1r_, nullptr, bc_M_, 1600, BK, 1600, D, 0, nullptr, 0, 0.f, 0, st));       // M[bk][tap][co] = W_tap s
+    RC(bc_class_sum_launch(bc_M_, bc_T_, BK, 1, st));
+    RC(bc_layer1_launch(bc_P1_, bc_T_, P("_dec._decoder.0.m.bias"), bc_c1_, BK, S, st));
+    RC(conv_layer_fwd(bc_c1_, bc_pk_[0], P("_dec._decoder.1.m.bias"), bc_c2_, BK, S, S, 5, 64, 1, nullptr, nullptr, st));
+    RC(conv_layer_fwd(bc_c2_, bc_pk_[1], P("_dec._decoder.2.m.bias"), bc_c3_, BK, S, S, 5, 64, 1, nullptr, nullptr, st));
+    RC(bc_c4_fwd_launch(bc_c3_, bc_Wk4_, P("_dec._decoder.3.bias"), bc_out4_, BK, S, st));
+    RC(bc_mix_launch(bc_out4_, last_.obs, recon_, bc_dout4_, metrics_ + 0, B, K, S, cfg.obs_channels, scratch_, scratch_floats_, st));
+    return 0;
+}
+
+int SlateModel::bwd_bcdec(hipStream_t st) {
+    const int B = last_.B, BK = B * K;
+    const long long BKN = (long long)BK * N;
+    // output conv 64 -> 4
+    const int nb = bc_c4_wgrad_blocks(BK, S);
+    RC(bc_c4_wgrad_launch(bc_c3_, bc_dout4_, scratch_, BK, S, st));
+    RC(colsum_launch(scratch_, 4 * 64 * 9, G("_dec._decoder.3.weight"), nb, 4 * 64 * 9, 0, 1.f, scratch_ + (size_t)nb * 2304, scratch_floats_ - (size_t)nb * 2304, st));
+    RC(colsum_launch(bc_dout4_, 4, G("_dec._decoder.3.bias"), BKN, cfg.obs_channels + 1, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(bc_c4_bwd_data_launch(bc_dout4_, bc_Wb4_, bc_c3_, bc_gA_, BK, S, st));                                      // gA = d c3 (pre-relu)
+    RC(conv_layer_wgrad(bc_c2_, bc_gA_, G("_dec._decoder.2.m.weight"), G("_dec._decoder.2.m.bias"), BK, S, S, 5, 64, 64, st));
+    RC(conv_layer_fwd(bc_gA_, bc_pkb_[1], nullptr, bc_gB_, BK, S, S, 5, 64, 0, nullptr, bc_c2_, st));               // gB = d c2 (pre-relu)
+    RC(conv_layer_wgrad(bc_c1_, bc_gB_, G("_dec._decoder.1.m.weight"), G("_dec._decoder.1.m.bias"), BK, S, S, 5, 64, 64, st));
+    RC(conv_layer_fwd(bc_gB_, bc_pkb_[0], nullptr, bc_gA_, BK, S, S, 5, 64, 0, nullptr, bc_c1_, st));               // gA = d c1 (pre-relu)
+    // first layer through the shortcut
+    RC(fill_launch(bc_dT_, (long long)BK * 1600, 0.f, st));
+    RC(bc_layer1_bwd_launch(bc_gA_, bc_dT_, BK, S, st));
+    RC(colsum_launch(bc_dT_, 64, G("_dec._decoder.0.m.bias"), (long long)BK * 25, 64, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(bc_class_sum_launch(bc_dT_, bc_dM_, BK, 0, st));
+    RC(lin_bwd_x(bc_dM_, 1600, bc_W1r_, gslots_, D, BK, 1600, D, nullptr, 0, nullptr, 0, st));                      // d slots
+    RC(lin_bwd_w(bc_dM_, 1600, slots_, D, bc_dW1r_, nullptr, BK, 1600, D, 1.f, st));
+    RC(colsum_launch(bc_gA_, (long long)N * 64, bc_G1_, BK, N * 64, 0, 1.f, scratch_, scratch_floats_, st));        // sum over (image, slot)
+    RC(bc_posconv_bwd_launch(bc_G1_, bc_dWc_, S, st));
+    RC(bc_compose_bwd_launch(P("_dec._decoder.0.m.weight"), P("_dec._pos_emb.channels_map.weight"), P("_dec._pos_emb.channels_map.bias"), bc_dWc_,
+                             bc_dW1r_, G("_dec._decoder.0.m.weight"), G("_dec._pos_emb.channels_map.weight"), G("_dec._pos_emb.channels_map.bias"), D, st));
     return 0;
 }

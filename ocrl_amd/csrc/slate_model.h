@@ -13,6 +13,7 @@ struct SlateConfig {
     int num_blocks = 4, num_heads = 4;
     float dropout = 0.1f;
     int max_batch = 1;
+    int use_bcdec = 0;      // Slot-Attention configuration: spatial-broadcast decoder instead of dVAE + transformer
 };
 
 struct ParamInfo {
@@ -78,6 +79,9 @@ private:
     int bwd_decoder(hipStream_t st);
     int bwd_encoder(hipStream_t st);
     int bwd_dvae(hipStream_t st);
+    int pack_bcdec(hipStream_t st);
+    int fwd_bcdec(hipStream_t st);
+    int bwd_bcdec(hipStream_t st);
 
     std::vector<ParamInfo> params_;
     std::map<std::string, int> index_;
@@ -125,4 +129,7 @@ private:
     float *gA_, *gB_;                     // [B*N,64] (CNN encoder / slot-attention input gradients)
     float *gdA_, *gdB_;                   // dVAE decoder gradient ping-pong (up to [B*4T,256])
     float *gmap_;
+    // broadcast decoder (use_bcdec)
+    float *bc_Wc_, *bc_W1r_, *bc_P1_, *bc_M_, *bc_T_, *bc_c1_, *bc_c2_, *bc_c3_, *bc_out4_, *bc_dout4_, *bc_gA_, *bc_gB_;
+    float *bc_pk_[2], *bc_pkb_[2], *bc_Wk4_, *bc_Wb4_, *bc_dW1r_, *bc_dWc_, *bc_dT_, *bc_dM_, *bc_G1_;
 };

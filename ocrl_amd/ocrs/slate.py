@@ -44,7 +44,8 @@ def _dims(ocr_config, env_config):
         vocab_size=int(ocr_config.dvae.vocab_size), d_model=int(ocr_config.dvae.d_model), cnn_hidden=int(ocr_config.cnn.hidden_size),
         num_slots=int(sa.num_slots), num_iterations=int(sa.num_iterations), slot_size=int(sa.slot_size),
         mlp_hidden=int(sa.mlp_hidden_size), num_dec_blocks=int(ocr_config.tfdec.num_dec_blocks),
-        num_dec_heads=int(ocr_config.tfdec.num_dec_heads), dropout=float(ocr_config.learning.dropout))
+        num_dec_heads=int(ocr_config.tfdec.num_dec_heads), dropout=float(ocr_config.learning.dropout),
+        use_bcdec=bool(ocr_config.use_bcdec))
 
 
 def _position_grid(S):
@@ -97,8 +98,6 @@ class SLATE_Module(nn.Module):
         self._obs_channels = int(env_config.obs_channels)
         self._use_cnn_feat = bool(ocr_config.use_cnn_feat)
         self._use_bcdec = bool(ocr_config.use_bcdec)
-        if self._use_bcdec:
-            raise NotImplementedError("ocr.use_bcdec=True (Slot-Attention broadcast decoder) is not built yet on the HIP backend")
         self._dims = _dims(ocr_config, env_config)
         self._vocab_size = self._dims.vocab_size
         self._num_slots = self._dims.num_slots
@@ -143,7 +142,7 @@ class SLATE_Module(nn.Module):
         L = _lib.lib()
         d = self._dims
         c = _lib.SlateConfig(d.obs_size, d.obs_channels, d.vocab_size, d.d_model, d.cnn_hidden, d.num_slots, d.num_iterations,
-                             d.slot_size, d.mlp_hidden, d.num_dec_blocks, d.num_dec_heads, d.dropout, 1)
+                             d.slot_size, d.mlp_hidden, d.num_dec_blocks, d.num_dec_heads, d.dropout, 1, int(d.use_bcdec))
         h = ctypes.c_void_p()
         _lib.check(L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)))
         out = []
@@ -284,22 +283,28 @@ class SLATE_Module(nn.Module):
         B = obs.shape[0]
         noise, self._injected_noise = self._injected_noise, None
         m = self.engine.forward(obs, self._tau, self.training, self._next_seed(), noise)
-        metrics = {
-            "loss": m[2],
-            "dvae_mse": m[0],
-            "cross_entropy": m[1],
-            "tau": torch.Tensor([self._tau]),
-        }
+        if self._use_bcdec:        # slate_module.py:218-225
+            metrics = {"loss": m[2], "mse": m[0].detach(), "ari": 0}
+        else:
+            metrics = {
+                "loss": m[2],
+                "dvae_mse": m[0],
+                "cross_entropy": m[1],
+                "tau": torch.Tensor([self._tau]),
+            }
         if masks is not None:
             from ..utils.tools import calculate_ari
             import numpy as np
             attns = self._attns_image(B)
             fg_mask = 1 - masks[:, -1].unsqueeze(1)
             attns = torch.cat([attns * fg_mask, fg_mask], dim=1)
-            metrics["ari"] = float(np.mean(calculate_ari(masks, attns)))
+            if self._use_bcdec:     # the SLATE branch of the reference computes but does not report ari (slate_module.py:231)
+                metrics["ari"] = float(np.mean(calculate_ari(masks, attns)))
         if with_mse:
             raise NotImplementedError("with_mse (autoregressive image generation) is not built yet on the HIP backend")
         if with_rep:
+            if self._use_bcdec:
+                raise NotImplementedError("with_rep is not available with use_bcdec on the HIP backend (the dVAE forward is skipped)")
             E, V = self._enc_size, self._vocab_size
             z = self.engine.tensor("z", (B, E, E, V)).permute(0, 3, 1, 2)
             return metrics, z
@@ -317,7 +322,7 @@ class SLATE_Module(nn.Module):
         self.eval()
         self.engine.forward(obs, self._tau, False, self._next_seed(), None)
         self.train(was)
-        recon = self.engine.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2)
+        recon = self.engine.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2)     # dVAE or broadcast-decoder reconstruction
         attns = self._attns_image(B)
         attns = obs.unsqueeze(1) * attns + (1.0 - attns)
         return {"samples": for_viz(visualize([obs, recon, attns]))}

@@ -20,16 +20,17 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.ocrl_abi_version() == 1
+    assert L.ocrl_abi_version() == 2
 
 
-@pytest.mark.parametrize("over", [dict(obs_size=64), dict(obs_size=128, num_slots=6), dict(obs_size=16, vocab_size=256, num_dec_blocks=2)])
+@pytest.mark.parametrize("over", [dict(obs_size=64), dict(obs_size=128, num_slots=6), dict(obs_size=16, vocab_size=256, num_dec_blocks=2),
+                                  dict(obs_size=32, num_slots=6, use_bcdec=True)])
 def test_param_table_matches_reference_inventory(over):
     from ocrl_amd import _lib
     L = _lib.lib()
     cfg = O.default_cfg(**over)
     c = _lib.SlateConfig(cfg.obs_size, 3, cfg.vocab_size, cfg.d_model, cfg.cnn_hidden, cfg.num_slots, cfg.num_iterations, cfg.slot_size,
-                         cfg.mlp_hidden, cfg.num_dec_blocks, cfg.num_dec_heads, cfg.dropout, 2)
+                         cfg.mlp_hidden, cfg.num_dec_blocks, cfg.num_dec_heads, cfg.dropout, 2, int(cfg.use_bcdec))
     h = ctypes.c_void_p()
     _lib.check(L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)))
     try:
@@ -59,7 +60,7 @@ def test_param_table_matches_reference_inventory(over):
 def test_invalid_config_is_rejected_with_message():
     from ocrl_amd import _lib
     L = _lib.lib()
-    c = _lib.SlateConfig(30, 3, 4096, 192, 64, 6, 3, 192, 192, 4, 4, 0.1, 1)      # obs_size not a multiple of 4
+    c = _lib.SlateConfig(30, 3, 4096, 192, 64, 6, 3, 192, 192, 4, 4, 0.1, 1, 0)      # obs_size not a multiple of 4
     h = ctypes.c_void_p()
     assert L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)) != 0
     assert b"invalid" in L.ocrl_last_error()

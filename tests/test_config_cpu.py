@@ -91,8 +91,8 @@ def test_slate_surface_matches_reference_names():
     assert set(ck) == {"ocr_module_state_dict", "ocr_opt_state_dict"} and set(ck["ocr_opt_state_dict"]) == {"state", "param_groups"}
     with pytest.raises(RuntimeError):
         m.to("cpu")
-    with pytest.raises(NotImplementedError):
-        ocrs.SLATE(compose(CFG, "train_ocr", ["ocr=slotattn", "dataset=random-N5C4S4S2"]).ocr, c.dataset)
+    sa = ocrs.SLATE(compose(CFG, "train_ocr", ["ocr=slotattn", "dataset=random-N5C4S4S2"]).ocr, c.dataset)
+    assert "_dec._decoder.3.weight" in sa._module.state_dict() and "_dec._pos_emb.linear_position_embedding" not in sd
 
 
 def test_schedules_match_oracle():

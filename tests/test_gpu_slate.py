@@ -200,3 +200,51 @@ def test_device_rng_statistics():
     eps = (s0 - mu) / sig
     assert abs(eps.mean().item()) < 0.1 and abs(eps.std().item() - 1.0) < 0.1
     assert torch.isfinite(out[0][0][:3]).all()
+
+
+BC = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=1, use_bcdec=True)
+BC32 = dict(obs_size=32, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, use_bcdec=True)
+
+
+@pytest.mark.parametrize("tag,over,B", [("bcdec16", BC, 2), ("bcdec32", BC32, 3)])
+def test_broadcast_decoder_config_matches_oracle(tag, over, B):
+    """Slot-Attention configuration (use_bcdec): loss, reconstruction, every gradient, then two update() steps"""
+    cfg = O.default_cfg(**over)
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    S, K, D = cfg.obs_size, cfg.num_slots, cfg.slot_size
+    obs = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(21))
+    tr = O.OracleTrainer(cfg, P)
+    for step in range(2):
+        noise = O.make_noise(cfg, B, 30 + step)
+        tau, lrs = O.schedules(cfg, step)
+        tr2 = O.OracleTrainer(cfg, {n: p.detach() for n, p in tr.P.items()})
+        res = tr2.loss_and_grads(obs, noise, step, None)
+        eng.forward(obs.cuda(), tau, train=False, seed=step, noise=dict(slots=noise["slots"].cuda()))
+        eng.backward()
+        torch.cuda.synchronize()
+        m = eng.metrics.cpu()
+        el = abs(m[2].item() - res["loss"].item()) / abs(res["loss"].item())
+        er = relerr(eng.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2), res["recon_bc"])
+        es = relerr(eng.tensor("slots", (B, K, D)), res["slots"])
+        gmax = max(tr2.P[p.name].grad.abs().max().item() for p in eng.params if tr2.P[p.name].grad is not None)
+        worst, rows = 0.0, []
+        for p in eng.params:
+            ref = tr2.P[p.name].grad
+            got = eng.view(eng.flat_g, p)
+            if ref is None:
+                assert float(got.abs().max()) == 0.0, p.name          # no gradient in this mode
+                continue
+            e = relerr(got, ref.reshape(p.shape), floor=1e-5 * gmax)
+            rows.append((e, p.name))
+            worst = max(worst, e)
+        rows.sort(reverse=True)
+        log(f"[{tag}] step {step}: loss {el:.2e} recon {er:.2e} slots {es:.2e} grads worst {worst:.2e}; top " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:5]))
+        assert el < 1e-5 and er < 1e-4 and es < 1e-4 and worst < 1e-3, rows[:5]
+        tr.update(obs, noise, step, None)
+        eng.clip_adam(lrs, cfg.clip)
+        torch.cuda.synchronize()
+        wp = max(relerr(eng.view(eng.flat_p, p), tr.P[p.name].reshape(p.shape)) for p in eng.params)
+        log(f"[{tag}] step {step}: worst param err after update {wp:.2e}")
+        assert wp < 1e-4
