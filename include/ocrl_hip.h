@@ -65,12 +65,16 @@ int ocrl_slate_forward(ocrl_slate* h, const float* obs, int B, float tau, int tr
 int ocrl_slate_backward(ocrl_slate* h, void* stream);
 /* SLATE_Module.forward (slate_module.py:181-196): slots [B,K,D] and attention [B,N,K] only. */
 int ocrl_slate_encode(ocrl_slate* h, const float* obs, int B, unsigned long long seed, const float* noise_slots, void* stream);
+/* SLATE_Module._gen_imgs (slate_module.py:163-179): greedy autoregressive token decode from the slots of the last
+ * forward/encode, then dVAE decode into the "recon" tensor; metrics[4] = sum (obs - recon_tf)^2 / B.  Destroys the
+ * activations of the last forward (no ocrl_slate_backward afterwards). */
+int ocrl_slate_generate(ocrl_slate* h, void* stream);
 /* clip_grad_norm_(params, clip, "inf") + Adam(3 groups).step() (base.py:65-72, slate.py:19-34):
  * grads are first scaled by grad_scale (1/world_size after an all-reduce sum), clip <= 0 disables
  * clipping, `step` is the 1-based Adam step count.  metrics[3] receives max|g| before scaling. */
 int ocrl_slate_clip_adam(ocrl_slate* h, const float lr[3], float clip, int step, float grad_scale, void* stream);
 int ocrl_slate_grad_norm(ocrl_slate* h, void* stream);
-/* device float[8]: [0] dvae_mse, [1] cross_entropy, [2] loss, [3] max|grad| */
+/* device float[8]: [0] dvae_mse (mse with use_bcdec), [1] cross_entropy, [2] loss, [3] max|grad|, [4] mse of ocrl_slate_generate */
 float* ocrl_slate_metrics(const ocrl_slate* h);
 /* Named tensors of the last step ("slots" [B,K,D], "attn" [B,N,K], "recon" [B,S,S,4], "tokens"
  * (int32) [B,T], "zraw"/"z" [B,T,V], "feats" [B,N,64], "dec_out" [B,T,d], "pred", "mem", "emb",

@@ -41,6 +41,7 @@ def lib():
     L.ocrl_slate_bind.argtypes = [p, p, p, p, p, p, c_size_t]
     L.ocrl_slate_forward.argtypes = [p, p, c_int, c_float, c_int, c_ulonglong, p, p, p, p]
     L.ocrl_slate_backward.argtypes = [p, p]
+    L.ocrl_slate_generate.argtypes = [p, p]
     L.ocrl_slate_encode.argtypes = [p, p, c_int, c_ulonglong, p, p]
     L.ocrl_slate_clip_adam.argtypes = [p, POINTER(c_float * 3), c_float, c_int, c_float, p]
     L.ocrl_slate_grad_norm.argtypes = [p, p]

@@ -727,6 +727,35 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
     if (i < n) dst[i] = src[i];
 }
 
+// tokens[b*T + t] = argmax_v pred[(b*T + t)*V + v] for one position t of every image (first index wins ties)
+__global__ __launch_bounds__(256) void argmax_pos_kernel(const float* __restrict__ pred, int* __restrict__ tokens, int T, int V, int t) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    const long long row = (long long)blockIdx.x * T + t;
+    const float* r = pred + row * V;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int v = threadIdx.x; v < V; v += 256) { const float x = r[v]; if (x > best) { best = x; bi = v; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) if (rv[k] > best || (rv[k] == best && ri[k] < bi)) { best = rv[k]; bi = ri[k]; }
+        tokens[row] = bi;
+    }
+}
+// z[row][v] = (v == tokens[row])
+__global__ void onehot_kernel(const int* __restrict__ tokens, float* __restrict__ z, long long n, int V) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    z[i] = (int)(i % V) == tokens[i / V] ? 1.f : 0.f;
+}
+
 // ================================================================== launchers
 #define GRID1D(n) dim3(cdiv((n), 256)), dim3(256)
 
@@ -921,5 +950,15 @@ int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float*
 int copy_launch(const float* src, float* dst, long long n, hipStream_t st) {
     hipLaunchKernelGGL(copy_kernel, GRID1D(n), 0, st, src, dst, n);
     OCRL_CHECK_LAUNCH("copy");
+    return 0;
+}
+int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_pos_kernel, dim3(B), dim3(256), 0, st, pred, tokens, T, V, t);
+    OCRL_CHECK_LAUNCH("argmax_pos");
+    return 0;
+}
+int onehot_launch(const int* tokens, float* z, long long rows, int V, hipStream_t st) {
+    hipLaunchKernelGGL(onehot_kernel, GRID1D(rows * V), 0, st, tokens, z, rows * V, V);
+    OCRL_CHECK_LAUNCH("onehot");
     return 0;
 }

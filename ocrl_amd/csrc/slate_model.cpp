@@ -373,6 +373,14 @@ int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
         RC(lin_fwd(de_[i - 1], 64, P(fmt("_dvae._encoder.%d.m.weight", i)), P(fmt("_dvae._encoder.%d.m.bias", i)), de_[i], 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
     RC(lin_fwd(de_[6], 64, P("_dvae._encoder.7.weight"), P("_dvae._encoder.7.bias"), zraw_, V, BT, V, 64, 0, nullptr, 0, 0.f, 0, st));
     RC(gumbel_softmax_launch(zraw_, in.noise_z, in.noise_zh, z_, tokens_, BT, V, in.tau, in.seed, st));
+    RC(dvae_decode(B, drecon_, st));
+    return 0;
+}
+
+// dVAE decoder on z_ -> recon_ (ocrs/common/models.py:24-37,44-45) and the reconstruction loss into metrics[0]
+int SlateModel::dvae_decode(int B, float* drecon, hipStream_t st) {
+    const long long BT = (long long)B * T, BN = (long long)B * N;
+    const int ch = cfg.obs_channels;
     // decoder
     RC(lin_fwd(z_, V, P("_dvae._decoder.0.m.weight"), P("_dvae._decoder.0.m.bias"), dd0_, 64, BT, 64, V, 1, nullptr, 0, 0.f, 0, st));
     RC(conv_layer_fwd(dd0_, dw_fwd_[0], P("_dvae._decoder.1.m.bias"), dd1_, B, E, E, 3, 64, 1, nullptr, nullptr, st));
@@ -386,12 +394,12 @@ int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
     RC(lin_fwd(dd8_, 64, P("_dvae._decoder.9.m.weight"), P("_dvae._decoder.9.m.bias"), dd9_, 256, 4 * BT, 256, 64, 1, nullptr, 0, 0.f, 0, st));
     RC(pixel_shuffle_launch(dd9_, ps2_, B, 2 * E, 2 * E, 64, 1, nullptr, st));
     RC(lin_fwd(ps2_, 64, P("_dvae._decoder.11.weight"), P("_dvae._decoder.11.bias"), recon_, 4, BN, ch, 64, 0, nullptr, 0, 0.f, 0, st));
-    RC(mse_launch(in.obs, recon_, drecon_, metrics_ + 0, B, ch, S, S, scratch_, scratch_floats_, st));
+    RC(mse_launch(last_.obs, recon_, drecon, metrics_ + (drecon ? 0 : 4), B, ch, S, S, scratch_, scratch_floats_, st));
     return 0;
 }
 
 // token embedding + transformer decoder + cross entropy (slate_module.py:141-156, transformer.py)
-int SlateModel::fwd_decoder(hipStream_t st) {
+int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
     const int B = last_.B;
     const long long BT = (long long)B * T;
     const float p = pdrop_;
@@ -429,7 +437,7 @@ int SlateModel::fwd_decoder(hipStream_t st) {
     }
     RC(layernorm_fwd_launch(xin, P("_tfdec.layer_norm.weight"), P("_tfdec.layer_norm.bias"), lnf_, lnf_mean_, lnf_rstd_, BT, d, st));
     RC(lin_fwd(lnf_, d, P("_out.weight"), nullptr, pred_, V, BT, V, d, 0, nullptr, 0, 0.f, 0, st));
-    RC(ce_launch(pred_, tokens_, metrics_ + 1, BT, V, B, 1, scratch_, scratch_floats_, st));   // pred_ <- d loss / d pred
+    if (with_ce) RC(ce_launch(pred_, tokens_, metrics_ + 1, BT, V, B, 1, scratch_, scratch_floats_, st));   // pred_ <- d loss / d pred
     return 0;
 }
 
@@ -466,6 +474,26 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
     RC(pack_weights(st));
     RC(fwd_encoder(in, st));
     have_fwd_ = false;
+    return 0;
+}
+
+// SLATE_Module._gen_imgs (slate_module.py:163-179): greedy autoregressive token decode from the projected slots,
+// then the dVAE decoder.  The reference re-runs the decoder on the growing prefix; the causal mask makes a full-length
+// pass with the not-yet-generated tokens as placeholders give the same logits at position t, so each of the T steps is
+// one full decoder forward here.  Clobbers the decoder activations: no backward() afterwards.  metrics[4] = mse.
+int SlateModel::generate(hipStream_t st) {
+    OCRL_REQUIRE(!cfg.use_bcdec, "generate: the autoregressive decoder is not part of the use_bcdec configuration");
+    OCRL_REQUIRE(last_.B > 0 && last_.obs, "generate: run forward or encode first");
+    const int B = last_.B;
+    pdrop_ = 0.f;
+    have_fwd_ = false;
+    OCRL_HIP(hipMemsetAsync(tokens_, 0, sizeof(int) * (size_t)B * T, st));
+    for (int t = 0; t < T; ++t) {
+        RC(fwd_decoder(st, false));
+        RC(argmax_pos_launch(pred_, tokens_, B, T, V, t, st));
+    }
+    RC(onehot_launch(tokens_, z_, (long long)B * T, V, st));
+    RC(dvae_decode(B, nullptr, st));
     return 0;
 }
 

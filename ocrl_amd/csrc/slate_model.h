@@ -50,6 +50,7 @@ public:
     int forward(const StepInputs& in, hipStream_t st);          // loss terms -> metrics()
     int backward(hipStream_t st);                               // fills the flat gradient buffer
     int encode(const StepInputs& in, hipStream_t st);           // slots + attention only (inference path)
+    int generate(hipStream_t st);                               // greedy autoregressive image from the last step's slots
     int clip_adam(const float lr[3], float clip, int step, float gscale, hipStream_t st);
     int grad_norm(hipStream_t st);                              // metrics()[3] = max |g|
     float* metrics() const { return metrics_; }                 // device float[8]: dvae_mse, ce, loss, grad absmax
@@ -75,7 +76,8 @@ private:
     int pack_weights(hipStream_t st);
     int fwd_encoder(const StepInputs& in, hipStream_t st);
     int fwd_dvae(const StepInputs& in, hipStream_t st);
-    int fwd_decoder(hipStream_t st);
+    int fwd_decoder(hipStream_t st, bool with_ce = true);
+    int dvae_decode(int B, float* drecon, hipStream_t st);
     int bwd_decoder(hipStream_t st);
     int bwd_encoder(hipStream_t st);
     int bwd_dvae(hipStream_t st);

@@ -115,6 +115,9 @@ class SlateEngine:
     def backward(self):
         _lib.check(self.L.ocrl_slate_backward(self.h, self.stream))
 
+    def generate(self):
+        _lib.check(self.L.ocrl_slate_generate(self.h, self.stream))
+
     def encode(self, obs, seed, slot_noise=None):
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous()
         self._keep = (obs, slot_noise)

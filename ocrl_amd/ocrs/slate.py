@@ -300,8 +300,10 @@ class SLATE_Module(nn.Module):
             attns = torch.cat([attns * fg_mask, fg_mask], dim=1)
             if self._use_bcdec:     # the SLATE branch of the reference computes but does not report ari (slate_module.py:231)
                 metrics["ari"] = float(np.mean(calculate_ari(masks, attns)))
-        if with_mse:
-            raise NotImplementedError("with_mse (autoregressive image generation) is not built yet on the HIP backend")
+        if with_mse and not self._use_bcdec:      # slate_module.py:234-237: autoregressive reconstruction error
+            metrics = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in metrics.items()}
+            self.engine.generate()
+            metrics["mse"] = self.engine.metrics[4].clone()
         if with_rep:
             if self._use_bcdec:
                 raise NotImplementedError("with_rep is not available with use_bcdec on the HIP backend (the dVAE forward is skipped)")
@@ -313,8 +315,14 @@ class SLATE_Module(nn.Module):
     def backward(self):
         self.engine.backward()
 
+    def _gen_imgs(self):
+        """slate_module.py:163-179 on the slots of the last forward: [B,3,S,S]"""
+        B, S = self.engine._keep[0].shape[0], self._obs_size
+        self.engine.generate()
+        return self.engine.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2).clone()
+
     def get_samples(self, obs) -> dict:
-        """slate_module.py:243-261 without the autoregressive decode: [obs | dVAE recon | whitened attention maps]"""
+        """slate_module.py:243-261: [obs | reconstruction | autoregressive reconstruction | whitened attention maps]"""
         from ..utils.tools import for_viz, visualize
         obs = self._need(obs)
         B, S = obs.shape[0], self._obs_size
@@ -322,10 +330,12 @@ class SLATE_Module(nn.Module):
         self.eval()
         self.engine.forward(obs, self._tau, False, self._next_seed(), None)
         self.train(was)
-        recon = self.engine.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2)     # dVAE or broadcast-decoder reconstruction
-        attns = self._attns_image(B)
+        recon = self.engine.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2).clone()   # dVAE or broadcast-decoder reconstruction
+        attns = self._attns_image(B).clone()
         attns = obs.unsqueeze(1) * attns + (1.0 - attns)
-        return {"samples": for_viz(visualize([obs, recon, attns]))}
+        if self._use_bcdec:
+            return {"samples": for_viz(visualize([obs, recon, attns]))}
+        return {"samples": for_viz(visualize([obs, recon, self._gen_imgs(), attns]))}
 
     def load_state_dict(self, state_dict, strict=True):
         sd = {k: v for k, v in state_dict.items()}

@@ -248,3 +248,40 @@ def test_broadcast_decoder_config_matches_oracle(tag, over, B):
         wp = max(relerr(eng.view(eng.flat_p, p), tr.P[p.name].reshape(p.shape)) for p in eng.params)
         log(f"[{tag}] step {step}: worst param err after update {wp:.2e}")
         assert wp < 1e-4
+
+
+def test_autoregressive_generation_matches_oracle():
+    """_gen_imgs (slate_module.py:163-179): greedy token decode + dVAE decode against a plain restatement on the oracle"""
+    import torch.nn.functional as F
+    cfg = O.default_cfg(**SMALL)
+    B = 2
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    obs = torch.rand(B, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    noise = O.make_noise(cfg, B, 4)
+    eng.forward(obs.cuda(), 1.0, train=False, seed=0, noise=dev_noise(cfg, noise))
+    eng.generate()
+    torch.cuda.synchronize()
+    T, V, E = 16, cfg.vocab_size, 4
+    # oracle: grow the prefix exactly as the reference does
+    feats = O.cnn_encode(P, obs)
+    slots, _ = O.slot_encoder(P, feats, noise["slots"], cfg)
+    mem = F.linear(slots, P["_slotproj.weight"])
+    inp = P["_bos_token._bos_token"].expand(B, 1, -1)
+    toks = []
+    for t in range(T):
+        dec = O.transformer_decoder(P, inp + P["_z_pos.pe"][:, :inp.shape[1]], mem, cfg)
+        nxt = F.linear(dec, P["_out.weight"])[:, -1].argmax(-1)
+        toks.append(nxt)
+        inp = torch.cat([inp, F.embedding(nxt, P["_dict.dictionary.weight"]).unsqueeze(1)], 1)
+    toks = torch.stack(toks, 1)
+    zg = F.one_hot(toks, V).float().transpose(1, 2).reshape(B, V, E, E)
+    rec = O.dvae_decode(P, zg)
+    got_tok = eng.tensor("tokens", (B, T), torch.int32).cpu().long()
+    assert torch.equal(got_tok, toks), (got_tok, toks)
+    e = relerr(eng.tensor("recon", (B, 16, 16, 4))[..., :3].permute(0, 3, 1, 2), rec)
+    mse = ((obs - rec) ** 2).sum() / B
+    em = abs(eng.metrics.cpu()[4].item() - mse.item()) / mse.item()
+    log(f"[gen_imgs] recon {e:.2e} mse {em:.2e}")
+    assert e < 1e-4 and em < 1e-5
