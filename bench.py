@@ -41,8 +41,13 @@ def cpu_baseline(obs_size, batch, steps):
     """the CPU oracle's update() (port of ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74) on the host cores"""
     from oracle import slate_oracle as O
     from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))      # the cores this process may actually use (not the host's total)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle update() on {cores} host threads, batch {batch}, {steps} timed steps", file=sys.stderr, flush=True)
     cfg = O.default_cfg(obs_size=obs_size, num_slots=6, num_iterations=3)
     tr = O.OracleTrainer(cfg, O.formula_params(cfg))
     obs = scenes_to_obs(random_sprite_scenes(batch, obs_size, seed=123))
@@ -53,6 +58,7 @@ def cpu_baseline(obs_size, batch, steps):
         masks = O.make_masks(cfg, batch, 1000 + step)
         tr.update(obs, noise, step, masks)
         times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline step {step}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
     t = sum(times[1:]) / steps
     return {"value": round(batch / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle update() SLATE {obs_size}x{obs_size}/6 slots/3 iters, batch {batch}, train mode dropout 0.1, "
@@ -133,6 +139,13 @@ def main():
     conv_flops = 2.0 * 25 * 64 * 64 * B * S * S
     conv_ms = ms[0] / max(cnt[0], 1)
     conv_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if cnt[0] else 0.0
+    traffic = None       # HBM bytes per launch from committed rocprofv3 PMC passes (same kernel, same shape), if present
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+        if B == 128 and S == 128:
+            traffic = tj["kernels"]["conv_fwd_kernel<5, 64, 64>"]["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": "images/sec (node) SLATE pretrain 128x128, 6 slots, 3 iters" if args.workload == "slate" else
                   "images/sec (node) Slot-Attention (use_bcdec) pretrain 128x128, 6 slots, 3 iters",
@@ -144,7 +157,7 @@ def main():
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<5,64,64> (CNN encoder 5x5 conv, fwd + bwd-data launches)",
                      "achieved": round(conv_tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(conv_tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                     "frac": round(conv_tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
                      "launches": int(cnt[0]), "avg_ms": round(conv_ms, 4)},
         "step_mfma_frac": round(ips / world * 3 * FWD_FLOP_PER_IMAGE.get(S, 0) / (PEAK_MFMA_F32_TFLOPS * 1e12), 4),
         "final_loss": round(loss, 4),
