@@ -115,11 +115,11 @@ static inline SaWts sa_wts_layout(int C, int D, int H) {
 }
 // Saved-activation matrix: one row per (image, iteration, slot), row = (b*I + t)*K + j, fields at fixed
 // column offsets, so every field is a strided [B*I*K, dim] GEMM operand with ld = sa_save_ld().
-struct SaSave { int sprev, sn, q, u, r, z, n, hn, sg, m, hid, qp, up, csum, ld; };
+struct SaSave { int sprev, sn, q, u, r, z, n, hn, sg, m, hid, qp, up, upn, csum, ld; };
 static inline SaSave sa_save_layout(int C, int D, int H) {
     SaSave o;
     o.sprev = 0; o.sn = D; o.q = 2 * D; o.u = 3 * D; o.r = 4 * D; o.z = 5 * D; o.n = 6 * D; o.hn = 7 * D; o.sg = 8 * D; o.m = 9 * D;
-    o.hid = 10 * D; o.qp = 10 * D + H; o.up = 10 * D + H + C; o.csum = 10 * D + H + 2 * C; o.ld = 10 * D + H + 2 * C + 4;
+    o.hid = 10 * D; o.qp = 10 * D + H; o.up = 10 * D + H + C; o.upn = 10 * D + H + 2 * C; o.csum = 10 * D + H + 3 * C; o.ld = 10 * D + H + 3 * C + 4;
     return o;
 }
 // Gradient rows emitted by the backward kernel (same row index), consumed by the weight-gradient GEMMs.

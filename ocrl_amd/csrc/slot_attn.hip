@@ -1,95 +1,106 @@
 // Fused slot attention (reference: ocrs/common/slot_attn.py:47-102), forward and backward.
 //
-// One workgroup (512 threads) per image runs ALL iterations in one launch; the slots, the query
-// and every slot-side intermediate stay in LDS between iterations.  The k/v projections are
-// folded algebraically so the [N,D] k and v tensors are never materialised:
+// One workgroup per image runs ALL iterations in one launch; the slots, the query and every slot-side
+// intermediate stay in LDS between iterations.  The k/v projections are folded algebraically so the [N,D] k and v
+// tensors are never materialised:
 //     logits[n,j] = LN(x)[n] . q'[j],   q' = scale * q Wk        (q' is [K,C], C = 64)
 //     updates[j]  = (sum_n w[n,j] LN(x)[n] / sum_n w[n,j]) Wv^T  (w = softmax_j(logits) + eps)
-// so each iteration streams x (N x 64 floats, 256 B per position) exactly once — 3x less HBM
-// traffic than re-reading k||v (N x 384) as the reference does; only the summation order differs.
-// Streaming layout: 8 lanes per position (two float4 each, 128 B contiguous per instruction),
-// per-row LayerNorm / logits reduced with 3 xor-shuffles inside the 8-lane group, the K x 64
-// weighted sums accumulated in registers and reduced across the workgroup once per iteration.
+// so each iteration streams x (N x 64 floats, 256 B per position) exactly once — 3x less HBM traffic than
+// re-reading k||v (N x 384) as the reference does; only the summation order differs.
 //
-// The backward recomputes attn from x and the saved q', streams x once per iteration (reverse
-// order) accumulating dq' in registers and d(LN(x)) into the dx buffer, and emits the per-slot
-// gradient rows that the weight-gradient GEMMs (slate_model.cpp) contract over (image, iter, slot).
+// Streaming pass (the HBM-bound part) on the matrix cores: a wave owns tiles of 16 positions; lane (i, g) loads
+// x[pos i][16c+4g .. +3] (c = 0..3), LayerNorm is reduced over the 4 lanes of a position with two xor-shuffles, and
+//     logits[16 pos x 16 slots]   = 16 x v_mfma_f32_16x16x4_f32 (slots padded to 16, q' in registers)
+//     P^T[64 ch x 16 slots]      += 16 x MFMA with the softmax weights straight from the accumulator registers
+// (LN(x)^T comes back through a per-wave LDS tile).  The backward adds d attn = LN(x).dU', dq'^T and
+// d LN(x) = w dU' + dlogits q' (64 MFMAs per tile), pushes d LN(x) through the LayerNorm backward in the load
+// layout and accumulates it into the dx buffer.  Per-slot gradient rows are emitted for the weight-gradient GEMMs
+// (slate_model.cpp) which contract over (image, iteration, slot).
 //
-// All weights come from ONE packed block, all saved activations / gradient rows go to ONE
-// row-matrix each (kernels.h: sa_*_layout): few base pointers keep the kernels out of scratch.
+// All weights come from ONE packed block, all saved activations / gradient rows go to ONE row-matrix each
+// (kernels.h: sa_*_layout): few base pointers keep the kernels out of scratch.
 #include "common.h"
 #include "kernels.h"
 
-#define SA_THREADS 512
-#define SA_WAVES 8
 #define SA_C 64
-#define SA_PF 2      // positions in flight per 8-lane group (x2: current + next)
-#define SA_PFB 1     // same for the backward pass (register budget)
+#define SA_TF 1024        // forward threads per workgroup (16 waves)
+#define SA_TB 512         // backward threads per workgroup (8 waves)
+#define SA_TLD 68         // row stride of the per-wave [16 positions][64 channels] LDS tile
+#define SA_WLD 17         // row stride of the per-wave [16 positions][16 slots] LDS tiles
 
-__device__ inline float grp8_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    return v;
-}
-__device__ inline float rows_sum(float v) {   // across the 8 row-groups of a wave (same l8)
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ inline float red16_sum(float v) {          // over the 16 lanes sharing lane>>4
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ inline float red16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+__device__ inline float redg_sum(float v) {           // over the 4 lanes of one position (same lane & 15)
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
 
-// out[j][col] = scale * sum_e in[j][e] * Wt[e*ldw + col] + bias[col],  col < NC, j < K   (in/out in LDS)
+// out[j][col] = scale * sum_e in[j][e] * Wt[e*ldw + col] + bias[col],  col < NC, j < K   (in/out in LDS).
+// Thread = (E-slice g, column): the reduction over e is split over blockDim/NC thread groups and combined through
+// `scr` ([G][K][NC] floats) in a fixed order.  Ends with a workgroup barrier.
 template <int K>
-__device__ __noinline__ void matvec(const float* __restrict__ Wt, int ldw, int E, int NC, const float* in, int ldin,
-                                    float* out, int ldout, const float* __restrict__ bias, float scale) {
-    for (int col = threadIdx.x; col < NC; col += SA_THREADS) {
+__device__ __forceinline__ void matvec(const float* __restrict__ Wt, int ldw, int E, int NC, const float* in, int ldin,
+                                    float* out, int ldout, const float* __restrict__ bias, float scale, float* scr) {
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int ncp = (NC + 63) & ~63;
+    int G = nt / ncp;
+    if (G > 16) G = 16;
+    if (G <= 1) {
+        for (int col = tid; col < NC; col += nt) {
+            float acc[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) acc[j] = 0.f;
+#pragma unroll 4
+            for (int e = 0; e < E; ++e) {
+                const float w = Wt[e * ldw + col];
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc[j] += in[j * ldin + e] * w;
+            }
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) out[j * ldout + col] = acc[j] * scale + bv;
+        }
+        __syncthreads();
+        return;
+    }
+    const int g = tid / ncp, col = tid - g * ncp;
+    if (g < G && col < NC) {
         float acc[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) acc[j] = 0.f;
 #pragma unroll 4
-        for (int e = 0; e < E; ++e) {
+        for (int e = g; e < E; e += G) {
             const float w = Wt[e * ldw + col];
 #pragma unroll
             for (int j = 0; j < K; ++j) acc[j] += in[j * ldin + e] * w;
         }
-        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int j = 0; j < K; ++j) out[j * ldout + col] = acc[j] * scale + bv;
+        for (int j = 0; j < K; ++j) scr[(g * K + j) * NC + col] = acc[j];
     }
-}
-// same for NC == 64 outputs: the E range is split over the 8 waves and reduced through `scr` ([8][K][64])
-template <int K>
-__device__ __noinline__ void matvec64_split(const float* __restrict__ Wt, int ldw, int E, const float* in, int ldin,
-                                            float* out, int ldout, float scale, float* scr) {
-    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int per = (E + SA_WAVES - 1) / SA_WAVES;
-    const int e0 = g * per, e1 = min(E, e0 + per);
-    float acc[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) acc[j] = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const float w = Wt[e * ldw + col];
-#pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] += in[j * ldin + e] * w;
-    }
-#pragma unroll
-    for (int j = 0; j < K; ++j) scr[(g * K + j) * 64 + col] = acc[j];
     __syncthreads();
-    for (int i = threadIdx.x; i < K * 64; i += SA_THREADS) {
+    for (int i = tid; i < K * NC; i += nt) {
+        const int j = i / NC, c = i - j * NC;
         float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < SA_WAVES; ++w) s += scr[w * K * 64 + i];
-        out[(i >> 6) * ldout + (i & 63)] = s * scale;
+        for (int w = 0; w < G; ++w) s += scr[(w * K + j) * NC + c];
+        out[j * ldout + c] = s * scale + (bias ? bias[c] : 0.f);
     }
     __syncthreads();
 }
 
 // LayerNorm of K rows of width D held in LDS (one wave per row).
 __device__ __noinline__ void ln_rows(const float* in, float* out, const float* __restrict__ g, const float* __restrict__ b, int K, int D) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j = wv; j < K; j += SA_WAVES) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wv; j < K; j += nw) {
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += in[j * D + c];
         const float mu = wave_sum(s) / D;
@@ -102,8 +113,8 @@ __device__ __noinline__ void ln_rows(const float* in, float* out, const float* _
 // dx[j] (+)= LN backward of rows; accumulates dgamma/dbeta (LDS, atomics)
 __device__ __noinline__ void ln_rows_bwd(const float* dy, const float* xin, float* dx, int accumulate, const float* __restrict__ g,
                                          float* dgam, float* dbet, int K, int D) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j = wv; j < K; j += SA_WAVES) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wv; j < K; j += nw) {
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += xin[j * D + c];
         const float mu = wave_sum(s) / D;
@@ -131,132 +142,111 @@ __device__ __noinline__ void ln_rows_bwd(const float* dy, const float* xin, floa
 
 // copy K rows of width W between LDS ([K][W]) and a row matrix (row stride ld)
 __device__ inline void rows_to_global(const float* lds, float* g, int ld, int K, int W) {
-    for (int i = threadIdx.x; i < K * W; i += SA_THREADS) { const int j = i / W, c = i - j * W; g[j * ld + c] = lds[i]; }
+    for (int i = threadIdx.x; i < K * W; i += blockDim.x) { const int j = i / W, c = i - j * W; g[j * ld + c] = lds[i]; }
 }
 __device__ inline void rows_from_global(float* lds, const float* g, int ld, int K, int W) {
-    for (int i = threadIdx.x; i < K * W; i += SA_THREADS) { const int j = i / W, c = i - j * W; lds[i] = g[j * ld + c]; }
+    for (int i = threadIdx.x; i < K * W; i += blockDim.x) { const int j = i / W, c = i - j * W; lds[i] = g[j * ld + c]; }
 }
 
-// ---- per-position LayerNorm(norm_inputs) for this lane's 8 channels; returns rstd, fills xh (normalised) and v (affine)
-__device__ inline float ln8(const float4& a, const float4& b, const float* gam, const float* bet, float* xh, float* v) {
-    constexpr int C = SA_C;
-    float t[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+// one 16-position tile for lane (i = lane & 15, g = lane >> 4): x[pos i][16c + 4g .. +3], c = 0..3 (zeros beyond N)
+__device__ inline void sa_load_tile(const float4* __restrict__ xb, int N, int t, int li, int g, float4 (&v)[4]) {
+    const int pos = t * 16 + li;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = pos < N ? xb[pos * 16 + 4 * c + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// LayerNorm(norm_inputs) statistics of a position spread over its 4 lanes: xn = (x - mean) * rstd; returns rstd.
+// The affine part is folded into the slot-side operands: LN(x).q' = xn.(gamma q') + beta.q'.
+__device__ inline float sa_ln16(const float4 (&v)[4], float* xn) {
+    float t[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
     float s1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s1 += t[i];
-    const float mu = grp8_sum(s1) * (1.0f / C);
+    for (int k = 0; k < 16; ++k) s1 += t[k];
+    const float mu = redg_sum(s1) * (1.0f / SA_C);
     float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { t[i] -= mu; s2 += t[i] * t[i]; }
-    const float rs = rsqrtf(grp8_sum(s2) * (1.0f / C) + 1e-5f);
+    for (int k = 0; k < 16; ++k) { t[k] -= mu; s2 += t[k] * t[k]; }
+    const float rs = rsqrtf(redg_sum(s2) * (1.0f / SA_C) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { xh[i] = t[i] * rs; v[i] = xh[i] * gam[i] + bet[i]; }
+    for (int k = 0; k < 16; ++k) xn[k] = t[k] * rs;
     return rs;
+}
+// qg[j][c] = gamma[c] v[j][c],  qb[j] = sum_c beta[c] v[j][c]   (v, qg: [K][64] in LDS; one wave per row)
+__device__ inline void sa_fold_affine(const float* v, const float* __restrict__ gam, const float* __restrict__ bet, float* qg, float* qb, int K) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wv; j < K; j += nw) {
+        const float x = v[j * SA_C + lane];
+        qg[j * SA_C + lane] = x * gam[lane];
+        const float sb = wave_sum(x * bet[lane]);
+        if (lane == 0) qb[j] = sb;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- forward streaming pass
-// accumulates  scr[wave][j][0..63] = sum_n w[n,j] LN(x)[n],  scr[wave][j][64] = sum_n w[n,j]
+// scr[wave][j][0..63] = sum_n w[n,j] xn[n],  scr[wave][j][64] = sum_n w[n,j]   (scr aliases the tiles: barrier inside)
 template <int K>
-__device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int N, const float* qp, const float* __restrict__ ln_g,
-                                           const float* __restrict__ ln_b, float eps, float* attn_out, float* scr) {
-    constexpr int C = SA_C;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = tid >> 3, l8 = tid & 7;
-    constexpr bool QREG = (K <= 6);          // q' in registers while they last, else broadcast LDS reads
-    float gam[8], bet[8], qr[QREG ? K : 1][8], acc[K][8], csum[K];
+__device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int N, const float* qg, const float* qb, float eps, float* attn_out,
+                                              float* tiles, float* scr) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
+    float* tile = tiles + wv * 16 * SA_TLD;
+    float qpr[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = (i >> 2) * 32 + 4 * l8 + (i & 3);
-        gam[i] = ln_g[c];
-        bet[i] = ln_b[c];
-    }
+    for (int k = 0; k < 16; ++k) qpr[k] = li < K ? qg[li * SA_C + 16 * (k >> 2) + 4 * g + (k & 3)] : 0.f;
+    const float l0 = li < K ? qb[li] : 0.f;
+    f32x4_t acc[4];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        csum[j] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (QREG) qr[j][i] = qp[j * C + (i >> 2) * 32 + 4 * l8 + (i & 3)];
-            acc[j][i] = 0.f;
-        }
-    }
-    const float4* qp4 = reinterpret_cast<const float4*>(qp);
-    float4 c0[SA_PF], c1[SA_PF];
-#pragma unroll
-    for (int k = 0; k < SA_PF; ++k) {
-        const int n = grp + 64 * k;
-        if (n < N) { c0[k] = xb[n * 16 + l8]; c1[k] = xb[n * 16 + 8 + l8]; }
-    }
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;
+    const int ntile = (N + 15) / 16;
+    float4 cur[4];
+    if (wv < ntile) sa_load_tile(xb, N, wv, li, g, cur);
 #pragma unroll 1
-    for (int base = grp; base < N; base += 64 * SA_PF) {
-        float4 n0[SA_PF], n1[SA_PF];
+    for (int t = wv; t < ntile; t += nw) {
+        float xn[16];
+        sa_ln16(cur, xn);
+        if (t + nw < ntile) sa_load_tile(xb, N, t + nw, li, g, cur);      // in flight during the MFMA / softmax phase
+        f32x4_t L = (f32x4_t){l0, l0, l0, l0};
 #pragma unroll
-        for (int k = 0; k < SA_PF; ++k) {
-            const int n = base + 64 * (SA_PF + k);
-            if (n < N) { n0[k] = xb[n * 16 + l8]; n1[k] = xb[n * 16 + 8 + l8]; }
+        for (int k = 0; k < 16; ++k) L = MFMA16(xn[k], qpr[k], L);           // L[r] = logits[pos 4g+r][slot li]
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<float4*>(tile + li * SA_TLD + 16 * c + 4 * g) = make_float4(xn[4 * c], xn[4 * c + 1], xn[4 * c + 2], xn[4 * c + 3]);
+        f32x4_t w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = li < K ? L[r] : -INFINITY;
+            const float mx = red16_max(x);
+            const float e = li < K ? __expf(x - mx) : 0.f;
+            const float a = e / red16_sum(e);
+            const int pos = t * 16 + 4 * g + r;
+            const bool ok = li < K && pos < N;
+            w[r] = ok ? a + eps : 0.f;
+            csum += w[r];
+            if (attn_out && ok) attn_out[pos * K + li] = a;
         }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < SA_PF; ++k) {
-            const int n = base + 64 * k;
-            if (n < N) {
-                float xh[8], v[8];
-                ln8(c0[k], c1[k], gam, bet, xh, v);
-                int lo = l8;
-                asm volatile("" : "+v"(lo));
-                float lg[K];
-                float mx = -INFINITY;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    float d = 0.f;
-                    if (QREG) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) d += v[i] * qr[j][i];
-                    } else {
-                        const float4 qa = qp4[j * 16 + lo], qb = qp4[j * 16 + 8 + lo];
-                        d = v[0] * qa.x + v[1] * qa.y + v[2] * qa.z + v[3] * qa.w + v[4] * qb.x + v[5] * qb.y + v[6] * qb.z + v[7] * qb.w;
-                    }
-                    lg[j] = grp8_sum(d);
-                    mx = fmaxf(mx, lg[j]);
-                }
-                float se = 0.f;
-#pragma unroll
-                for (int j = 0; j < K; ++j) { lg[j] = __expf(lg[j] - mx); se += lg[j]; }
-                const float inv = 1.0f / se;
-                float mine = 0.f;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float a = lg[j] * inv;
-                    if (l8 == j) mine = a;
-                    const float w = a + eps;
-                    csum[j] += w;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[j][i] += w * v[i];
-                }
-                if (attn_out && l8 < K) attn_out[n * K + l8] = mine;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < SA_PF; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
+            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(tile[(4 * g + r) * SA_TLD + 16 * m + li], w[r], acc[m]);   // sum_n w xn^T: [ch][slot]
+        __builtin_amdgcn_wave_barrier();
     }
+    csum = redg_sum(csum);
+    __syncthreads();          // every wave is done with its tile: the region is reused for the partials
+    if (li < K) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        csum[j] = rows_sum(csum[j]);
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = rows_sum(acc[j][i]);
-    }
-    if (lane < 8) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) scr[(wv * K + j) * (C + 1) + (i >> 2) * 32 + 4 * l8 + (i & 3)] = acc[j][i];
-            if (lane == 0) scr[(wv * K + j) * (C + 1) + C] = csum[j];
-        }
+            for (int r = 0; r < 4; ++r) scr[(wv * K + li) * (SA_C + 1) + 16 * m + 4 * g + r] = acc[m][r];
+        if (g == 0) scr[(wv * K + li) * (SA_C + 1) + SA_C] = csum;
     }
 }
 
 template <int K>
-__global__ __launch_bounds__(SA_THREADS) void slot_attn_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so) {
+__global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D, H = p.H, N = p.N;
     constexpr int C = SA_C;
+    const int nt = blockDim.x, nw = nt >> 6;
     float* s = sm;                       // [K][D] slots
     float* sn = s + K * D;               // [K][D]
     float* q = sn + K * D;               // [K][D]
@@ -266,14 +256,16 @@ __global__ __launch_bounds__(SA_THREADS) void slot_attn_fwd_kernel(SlotAttnArgs 
     float* hid = gh + K * 3 * D;         // [K][H]
     float* qp = hid + K * H;             // [K][C]
     float* up = qp + K * C;              // [K][C]
-    float* cs = up + K * C;              // [16]
-    float* scr = cs + 16;                // [8][K][C+1] (+ csum column)
+    float* qg = up + K * C;              // [K][C] gamma_in * q'
+    float* cs = qg + K * C;              // [16] weight sums
+    float* qb = cs + 16;                 // [16] beta_in . q'
+    float* tiles = qb + 16;              // [waves][16][SA_TLD]: streaming tiles, matvec / reduction scratch
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int KD = K * D;
     const float* W = p.wts;
-    for (int i = tid; i < KD; i += SA_THREADS) s[i] = p.slots0[(size_t)b * KD + i];
+    for (int i = tid; i < KD; i += nt) s[i] = p.slots0[(size_t)b * KD + i];
     __syncthreads();
     const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
 
@@ -283,29 +275,31 @@ __global__ __launch_bounds__(SA_THREADS) void slot_attn_fwd_kernel(SlotAttnArgs 
         if (sv) rows_to_global(s, sv + so.sprev, so.ld, K, D);
         ln_rows(s, sn, W + wo.ln_s_g, W + wo.ln_s_b, K, D);
         __syncthreads();
-        matvec<K>(W + wo.WqT, D, D, D, sn, D, q, D, nullptr, 1.f);
+        matvec<K>(W + wo.WqT, D, D, D, sn, D, q, D, nullptr, 1.f, tiles);
+        matvec<K>(W + wo.Wk, C, D, C, q, D, qp, C, nullptr, p.scale, tiles);
+        sa_fold_affine(qp, W + wo.ln_in_g, W + wo.ln_in_b, qg, qb, K);
         __syncthreads();
-        matvec64_split<K>(W + wo.Wk, C, D, q, D, qp, C, p.scale, scr);
         if (sv) {
             rows_to_global(sn, sv + so.sn, so.ld, K, D);
             rows_to_global(q, sv + so.q, so.ld, K, D);
             rows_to_global(qp, sv + so.qp, so.ld, K, C);
         }
         // ---- streaming pass over the N positions
-        sa_stream_fwd<K>(xb, N, qp, W + wo.ln_in_g, W + wo.ln_in_b, p.eps,
-                         (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, scr);
+        sa_stream_fwd<K>(xb, N, qg, qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, tiles, tiles);
         __syncthreads();
         if (tid < K) {
             float c0 = 0.f;
-            for (int w = 0; w < SA_WAVES; ++w) c0 += scr[(w * K + tid) * (C + 1) + C];
+            for (int w = 0; w < nw; ++w) c0 += tiles[(w * K + tid) * (C + 1) + C];
             cs[tid] = c0;
         }
         __syncthreads();
-        for (int i = tid; i < K * C; i += SA_THREADS) {
+        for (int i = tid; i < K * C; i += nt) {
             const int j = i >> 6, c = i & 63;
             float a = 0.f;
-            for (int w = 0; w < SA_WAVES; ++w) a += scr[(w * K + j) * (C + 1) + c];
-            up[i] = a / cs[j];
+            for (int w = 0; w < nw; ++w) a += tiles[(w * K + j) * (C + 1) + c];
+            a /= cs[j];                                                  // sum_n w xn / sum_n w
+            up[i] = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
+            if (sv) sv[j * so.ld + so.upn + c] = a;
         }
         __syncthreads();
         if (sv) {
@@ -313,12 +307,10 @@ __global__ __launch_bounds__(SA_THREADS) void slot_attn_fwd_kernel(SlotAttnArgs 
             if (tid < K) sv[tid * so.ld + so.csum] = cs[tid];
         }
         // ---- updates = U' Wv^T ; GRU ; residual MLP
-        matvec<K>(W + wo.WvT, D, C, D, up, C, u, D, nullptr, 1.f);
-        __syncthreads();
-        matvec<K>(W + wo.WihT, 3 * D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f);
-        matvec<K>(W + wo.WhhT, 3 * D, D, 3 * D, s, D, gh, 3 * D, W + wo.bhh, 1.f);
-        __syncthreads();
-        for (int i = tid; i < KD; i += SA_THREADS) {
+        matvec<K>(W + wo.WvT, D, C, D, up, C, u, D, nullptr, 1.f, tiles);
+        matvec<K>(W + wo.WihT, 3 * D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f, tiles);
+        matvec<K>(W + wo.WhhT, 3 * D, D, 3 * D, s, D, gh, 3 * D, W + wo.bhh, 1.f, tiles);
+        for (int i = tid; i < KD; i += nt) {
             const int j = i / D, c = i - j * D;
             const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
             const float z = sigmoidf_(gi[j * 3 * D + D + c] + gh[j * 3 * D + D + c]);
@@ -334,167 +326,154 @@ __global__ __launch_bounds__(SA_THREADS) void slot_attn_fwd_kernel(SlotAttnArgs 
         __syncthreads();
         ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, K, D);      // sn = m
         __syncthreads();
-        matvec<K>(W + wo.W0T, H, D, H, sn, D, hid, H, W + wo.b0, 1.f);
+        matvec<K>(W + wo.W0T, H, D, H, sn, D, hid, H, W + wo.b0, 1.f, tiles);
+        for (int i = tid; i < K * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
         __syncthreads();
-        for (int i = tid; i < K * H; i += SA_THREADS) hid[i] = fmaxf(hid[i], 0.f);
-        __syncthreads();
-        matvec<K>(W + wo.W2T, D, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
-        __syncthreads();
-        for (int i = tid; i < KD; i += SA_THREADS) s[i] = q[i] + u[i];
+        matvec<K>(W + wo.W2T, D, H, D, hid, H, u, D, W + wo.b2, 1.f, tiles);      // u = mlp out
+        for (int i = tid; i < KD; i += nt) s[i] = q[i] + u[i];
         if (sv) {
             rows_to_global(sn, sv + so.m, so.ld, K, D);
             rows_to_global(hid, sv + so.hid, so.ld, K, H);
         }
         __syncthreads();
     }
-    for (int i = tid; i < KD; i += SA_THREADS) p.slots[(size_t)b * KD + i] = s[i];
+    for (int i = tid; i < KD; i += nt) p.slots[(size_t)b * KD + i] = s[i];
 }
 
 // ------------------------------------------------------------------------------------------- backward streaming pass
-// recomputes attn; dqp partials -> scr[wave][j][c]; d LN(x) written (FIRST), accumulated, or (FINAL) pushed through
-// the LayerNorm backward into dx, with the norm_inputs gamma/beta gradients accumulated into dg_in/db_in (LDS).
+// recomputes attn from xn and the folded operands (qg = gamma q', qb = beta.q', dug = gamma dU', dub = beta.dU');
+// partials scr[wave][j][0..63] = sum_n dlogits[n,j] xn[n], scr[wave][j][64] = sum_n dlogits[n,j] (scr aliases the
+// tiles: barrier inside); d xn written (FIRST), accumulated, or (FINAL) pushed through the LayerNorm backward into dx.
 template <int K, bool FIRST, bool FINAL>
-__device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, float4* __restrict__ dxb, int N, const float* qp, const float* dup,
-                                           const float* cs, const float* ud, const float* __restrict__ ln_g, const float* __restrict__ ln_b,
-                                           float eps, float* scr, float* dg_in, float* db_in) {
-    constexpr int C = SA_C;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = tid >> 3, l8 = tid & 7;
-    float gam[8], bet[8], acc[K][8], icv[K], udv[K];
-    float dgin[8], dbin[8];
+__device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, float4* __restrict__ dxb, int N, const float* qg, const float* qb,
+                                              const float* dug, const float* dub, const float* cs, const float* ud, float eps, float* tiles,
+                                              float* scr) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
+    float* tile = tiles + wv * (16 * SA_TLD + 2 * 16 * SA_WLD);
+    float* wt0 = tile + 16 * SA_TLD;
+    float* wt1 = wt0 + 16 * SA_WLD;
+    float qpr[16], dur[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = (i >> 2) * 32 + 4 * l8 + (i & 3);
-        gam[i] = ln_g[c];
-        bet[i] = ln_b[c];
-        dgin[i] = 0.f;
-        dbin[i] = 0.f;
+    for (int k = 0; k < 16; ++k) {
+        const int ch = 16 * (k >> 2) + 4 * g + (k & 3);
+        qpr[k] = li < K ? qg[li * SA_C + ch] : 0.f;
+        dur[k] = li < K ? dug[li * SA_C + ch] : 0.f;
     }
+    // B operands of d xn[pos][ch] = sum_slot (wn[pos][slot] dug[slot][ch] + dl[pos][slot] qg[slot][ch]), slot = 4s + g
+    float duB[2][4], qpB[2][4];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-        icv[j] = 1.0f / cs[j];
-        udv[j] = ud[j];
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
-    }
-    // q' and dU' stay in LDS (broadcast float4 reads) so the registers go to the dq' accumulators
-    const float4* qp4 = reinterpret_cast<const float4*>(qp);
-    const float4* du4 = reinterpret_cast<const float4*>(dup);
-    float4 c0[SA_PFB], c1[SA_PFB];
+        for (int m = 0; m < 4; ++m) {
+            const int slot = 4 * s + g;
+            duB[s][m] = slot < K ? dug[slot * SA_C + 16 * m + li] : 0.f;
+            qpB[s][m] = slot < K ? qg[slot * SA_C + 16 * m + li] : 0.f;
+        }
+    const float icv = li < K ? 1.0f / cs[li] : 0.f, udv = li < K ? ud[li] : 0.f;
+    const float l0 = li < K ? qb[li] : 0.f, d0 = li < K ? dub[li] : 0.f;
+    f32x4_t acc[4];
 #pragma unroll
-    for (int k = 0; k < SA_PFB; ++k) {
-        const int n = grp + 64 * k;
-        if (n < N) { c0[k] = xb[n * 16 + l8]; c1[k] = xb[n * 16 + 8 + l8]; }
-    }
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float sdl = 0.f;
+    const int ntile = (N + 15) / 16;
+    float4 cur[4];
+    if (wv < ntile) sa_load_tile(xb, N, wv, li, g, cur);
 #pragma unroll 1
-    for (int base = grp; base < N; base += 64 * SA_PFB) {
-        float4 n0[SA_PFB], n1[SA_PFB];
+    for (int t = wv; t < ntile; t += nw) {
+        float4 nxt[4];
+        if (t + nw < ntile) sa_load_tile(xb, N, t + nw, li, g, nxt);
+        float xn[16];
+        const float rs = sa_ln16(cur, xn);
+        f32x4_t L = (f32x4_t){l0, l0, l0, l0}, DA = (f32x4_t){d0, d0, d0, d0};
 #pragma unroll
-        for (int k = 0; k < SA_PFB; ++k) {
-            const int n = base + 64 * (SA_PFB + k);
-            if (n < N) { n0[k] = xb[n * 16 + l8]; n1[k] = xb[n * 16 + 8 + l8]; }
+        for (int k = 0; k < 16; ++k) { L = MFMA16(xn[k], qpr[k], L); DA = MFMA16(xn[k], dur[k], DA); }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<float4*>(tile + li * SA_TLD + 16 * c + 4 * g) = make_float4(xn[4 * c], xn[4 * c + 1], xn[4 * c + 2], xn[4 * c + 3]);
+        f32x4_t dl, wn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = li < K ? L[r] : -INFINITY;
+            const float mx = red16_max(x);
+            const float e = li < K ? __expf(x - mx) : 0.f;
+            const float a = e / red16_sum(e);
+            const float da = (DA[r] - udv) * icv;                 // d attn[pos][slot] (0 for padded slots: icv = 0)
+            const float dot = red16_sum(a * da);
+            const bool ok = li < K && (t * 16 + 4 * g + r) < N;
+            dl[r] = ok ? a * (da - dot) : 0.f;                    // d logits
+            wn[r] = ok ? (a + eps) * icv : 0.f;                   // normalised weight
+            sdl += dl[r];
+            wt0[(4 * g + r) * SA_WLD + li] = wn[r];
+            wt1[(4 * g + r) * SA_WLD + li] = dl[r];
         }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < SA_PFB; ++k) {
-            const int n = base + 64 * k;
-            if (n < N) {
-                float xh[8], v[8];
-                const float rs = ln8(c0[k], c1[k], gam, bet, xh, v);
-                int lo = l8;                       // opaque copy: keeps the q'/dU' LDS reads inside the loop
-                asm volatile("" : "+v"(lo));
-                float lg[K], da[K];
-                float mx = -INFINITY;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float4 qa = qp4[j * 16 + lo], qb = qp4[j * 16 + 8 + lo];
-                    const float4 ua = du4[j * 16 + lo], ub = du4[j * 16 + 8 + lo];
-                    const float d0 = v[0] * qa.x + v[1] * qa.y + v[2] * qa.z + v[3] * qa.w + v[4] * qb.x + v[5] * qb.y + v[6] * qb.z + v[7] * qb.w;
-                    const float d1 = v[0] * ua.x + v[1] * ua.y + v[2] * ua.z + v[3] * ua.w + v[4] * ub.x + v[5] * ub.y + v[6] * ub.z + v[7] * ub.w;
-                    lg[j] = grp8_sum(d0);
-                    da[j] = (grp8_sum(d1) - udv[j]) * icv[j];       // d attn[n,j]
-                    mx = fmaxf(mx, lg[j]);
-                    __builtin_amdgcn_sched_barrier(0);               // keep each slot's LDS reads next to their use
-                }
-                float se = 0.f;
+            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(tile[(4 * g + r) * SA_TLD + 16 * m + li], dl[r], acc[m]);   // sum_n dl xn^T: [ch][slot]
+        f32x4_t Dx[4];
 #pragma unroll
-                for (int j = 0; j < K; ++j) { lg[j] = __expf(lg[j] - mx); se += lg[j]; }
-                const float inv = 1.0f / se;
-                float dot = 0.f;
+        for (int m = 0; m < 4; ++m) Dx[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < K; ++j) { lg[j] *= inv; dot += lg[j] * da[j]; }
-                float dv[8];
+        for (int s = 0; s < 2; ++s) {
+            const float wa = wt0[li * SA_WLD + 4 * s + g], da2 = wt1[li * SA_WLD + 4 * s + g];     // A layout: [pos li][slot 4s+g]
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dv[i] = 0.f;
+            for (int m = 0; m < 4; ++m) { Dx[m] = MFMA16(wa, duB[s][m], Dx[m]); Dx[m] = MFMA16(da2, qpB[s][m], Dx[m]); }
+        }
+        __builtin_amdgcn_wave_barrier();          // all reads of the xn tile are issued: reuse it to transpose d xn
 #pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float dl = lg[j] * (da[j] - dot);          // d logits[n,j]
-                    const float wn = (lg[j] + eps) * icv[j];          // normalised weight
-                    const float4 qa = qp4[j * 16 + lo], qb = qp4[j * 16 + 8 + lo];
-                    const float4 ua = du4[j * 16 + lo], ub = du4[j * 16 + 8 + lo];
-                    const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-                    const float uv[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        acc[j][i] += dl * v[i];
-                        dv[i] += wn * uv[i] + dl * qv[i];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (!FIRST) {
-                    const float4 o0 = dxb[n * 16 + l8], o1 = dxb[n * 16 + 8 + l8];
-                    dv[0] += o0.x; dv[1] += o0.y; dv[2] += o0.z; dv[3] += o0.w;
-                    dv[4] += o1.x; dv[5] += o1.y; dv[6] += o1.z; dv[7] += o1.w;
-                }
-                if (FINAL) {   // LayerNorm(norm_inputs) backward
-                    float m1 = 0.f, m2 = 0.f;
+            for (int r = 0; r < 4; ++r) tile[(4 * g + r) * SA_TLD + 16 * m + li] = Dx[m][r];
+        __builtin_amdgcn_wave_barrier();
+        float dv[16];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        dgin[i] += dv[i] * xh[i];
-                        dbin[i] += dv[i];
-                        dv[i] *= gam[i];
-                        m1 += dv[i];
-                        m2 += dv[i] * xh[i];
-                    }
-                    m1 = grp8_sum(m1) * (1.0f / C);
-                    m2 = grp8_sum(m2) * (1.0f / C);
+        for (int c = 0; c < 4; ++c) {
+            const float4 d4 = *reinterpret_cast<const float4*>(tile + li * SA_TLD + 16 * c + 4 * g);
+            dv[4 * c] = d4.x; dv[4 * c + 1] = d4.y; dv[4 * c + 2] = d4.z; dv[4 * c + 3] = d4.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int pos = t * 16 + li;
+        if (!FIRST && pos < N) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dv[i] = rs * (dv[i] - m1 - xh[i] * m2);
-                }
-                dxb[n * 16 + l8] = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                dxb[n * 16 + 8 + l8] = make_float4(dv[4], dv[5], dv[6], dv[7]);
+            for (int c = 0; c < 4; ++c) {
+                const float4 o = dxb[pos * 16 + 4 * c + g];
+                dv[4 * c] += o.x; dv[4 * c + 1] += o.y; dv[4 * c + 2] += o.z; dv[4 * c + 3] += o.w;
             }
         }
+        if (FINAL) {      // LayerNorm(norm_inputs) backward from d xn, in the load layout
+            float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < SA_PFB; ++k) { c0[k] = n0[k]; c1[k] = n1[k]; }
-    }
+            for (int k = 0; k < 16; ++k) { m1 += dv[k]; m2 += dv[k] * xn[k]; }
+            m1 = redg_sum(m1) * (1.0f / SA_C);
+            m2 = redg_sum(m2) * (1.0f / SA_C);
 #pragma unroll
-    for (int j = 0; j < K; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = rows_sum(acc[j][i]);
-    if (lane < 8) {
-#pragma unroll
-        for (int j = 0; j < K; ++j)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) scr[(wv * K + j) * C + (i >> 2) * 32 + 4 * l8 + (i & 3)] = acc[j][i];
-    }
-    if (FINAL) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { dgin[i] = rows_sum(dgin[i]); dbin[i] = rows_sum(dbin[i]); }
-        if (lane < 8) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = (i >> 2) * 32 + 4 * l8 + (i & 3);
-                atomicAdd(&dg_in[c], dgin[i]);
-                atomicAdd(&db_in[c], dbin[i]);
-            }
+            for (int k = 0; k < 16; ++k) dv[k] = rs * (dv[k] - m1 - xn[k] * m2);
         }
+        if (pos < N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dxb[pos * 16 + 4 * c + g] = make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+    }
+    sdl = redg_sum(sdl);
+    __syncthreads();
+    if (li < K) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[(wv * K + li) * (SA_C + 1) + 16 * m + 4 * g + r] = acc[m][r];
+        if (g == 0) scr[(wv * K + li) * (SA_C + 1) + SA_C] = sdl;
     }
 }
 
 template <int K>
-__global__ __launch_bounds__(SA_THREADS) void slot_attn_bwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, SaGrad go) {
+__global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, SaGrad go) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D, H = p.H, N = p.N;
     constexpr int C = SA_C;
+    const int nt = blockDim.x, nw = nt >> 6;
     float* ds = sm;                      // [K][D] gradient wrt the iteration output
     float* t0 = ds + K * D;              // [K][D] scratch
     float* t1 = t0 + K * D;              // [K][D] scratch
@@ -506,17 +485,23 @@ __global__ __launch_bounds__(SA_THREADS) void slot_attn_bwd_kernel(SlotAttnArgs 
     float* up = qp + K * C;              // [K][C]
     float* dup = up + K * C;             // [K][C]
     float* dqp = dup + K * C;            // [K][C]
-    float* cs = dqp + K * C;             // [16] csum
+    float* qg = dqp + K * C;             // [K][C] gamma_in * q'
+    float* dug = qg + K * C;             // [K][C] gamma_in * dU'
+    float* upn = dug + K * C;            // [K][C] pre-affine U'
+    float* cs = upn + K * C;             // [16] csum
     float* ud = cs + 16;                 // [16] up . dup
-    float* gacc = ud + 16;               // dgamma/dbeta accumulators: ln_s (2D), ln_m (2D), ln_in (2C)
-    float* scr = gacc + 4 * D + 2 * C;   // [8][K][C]
+    float* qb = ud + 16;                 // [16] beta_in . q'
+    float* dub = qb + 16;                // [16] beta_in . dU'
+    float* sdl = dub + 16;               // [16] sum_n dlogits
+    float* gacc = sdl + 16;              // dgamma/dbeta accumulators: ln_s (2D), ln_m (2D), ln_in (2C)
+    float* tiles = gacc + 4 * D + 2 * C; // [waves][16*SA_TLD + 2*16*SA_WLD]: streaming tiles, matvec / reduction scratch
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int KD = K * D;
     const float* W = p.wts;
-    for (int i = tid; i < KD; i += SA_THREADS) ds[i] = p.dslots[(size_t)b * KD + i];
-    for (int i = tid; i < 4 * D + 2 * C; i += SA_THREADS) gacc[i] = 0.f;
+    for (int i = tid; i < KD; i += nt) ds[i] = p.dslots[(size_t)b * KD + i];
+    for (int i = tid; i < 4 * D + 2 * C; i += nt) gacc[i] = 0.f;
     __syncthreads();
     float* dg_s = gacc;  float* db_s = gacc + D;
     float* dg_m = gacc + 2 * D;  float* db_m = gacc + 3 * D;
@@ -530,99 +515,129 @@ __global__ __launch_bounds__(SA_THREADS) void slot_attn_bwd_kernel(SlotAttnArgs 
         // ---- residual MLP backward: s_new = sg + W2 relu(W0 m + b0) + b2,  m = LN_m(sg)
         rows_to_global(ds, gr + go.out, go.ld, K, D);
         rows_from_global(t0, sv + so.sg, so.ld, K, D);
-        matvec<K>(W + wo.W2, H, D, H, ds, D, dhid, H, nullptr, 1.f);            // dhid[h] = sum_d ds[d] W2[d][h]
-        __syncthreads();
-        for (int i = tid; i < K * H; i += SA_THREADS) {
+        matvec<K>(W + wo.W2, H, D, H, ds, D, dhid, H, nullptr, 1.f, tiles);            // dhid[h] = sum_d ds[d] W2[d][h]
+        for (int i = tid; i < K * H; i += nt) {
             const int j = i / H, c = i - j * H;
             const float v = sv[j * so.ld + so.hid + c] > 0.f ? dhid[i] : 0.f;
             dhid[i] = v;
             gr[j * go.ld + go.hid + c] = v;
         }
         __syncthreads();
-        matvec<K>(W + wo.W0, D, H, D, dhid, H, t1, D, nullptr, 1.f);            // dm[e] = sum_h dhid[h] W0[h][e]
-        __syncthreads();
-        ln_rows_bwd(t1, t0, ds, 1, W + wo.ln_m_g, dg_m, db_m, K, D);            // ds = d s_gru
+        matvec<K>(W + wo.W0, D, H, D, dhid, H, t1, D, nullptr, 1.f, tiles);            // dm[e] = sum_h dhid[h] W0[h][e]
+        ln_rows_bwd(t1, t0, ds, 1, W + wo.ln_m_g, dg_m, db_m, K, D);                   // ds = d s_gru
         __syncthreads();
         // ---- GRU backward
-        for (int i = tid; i < KD; i += SA_THREADS) {
+        for (int i = tid; i < KD; i += nt) {
             const int j = i / D, c = i - j * D;
             const float* row = sv + j * so.ld + c;
             const float r = row[so.r], z = row[so.z], nn = row[so.n], hn = row[so.hn], h = row[so.sprev];
-            const float g = ds[i];
-            const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
-            const float dz_pre = g * (h - nn) * z * (1.f - z);
+            const float gg = ds[i];
+            const float dn_pre = gg * (1.f - z) * (1.f - nn * nn);
+            const float dz_pre = gg * (h - nn) * z * (1.f - z);
             const float dr_pre = dn_pre * hn * r * (1.f - r);
             dgi[j * 3 * D + c] = dr_pre; dgi[j * 3 * D + D + c] = dz_pre; dgi[j * 3 * D + 2 * D + c] = dn_pre;
             dgh[j * 3 * D + c] = dr_pre; dgh[j * 3 * D + D + c] = dz_pre; dgh[j * 3 * D + 2 * D + c] = dn_pre * r;
-            t2[i] = g * z;                 // dh (direct path)
+            t2[i] = gg * z;                // dh (direct path)
             t0[i] = h;                     // s_prev, for LN_s backward below
         }
         __syncthreads();
         rows_to_global(dgi, gr + go.gi, go.ld, K, 3 * D);
         rows_to_global(dgh, gr + go.gh, go.ld, K, 3 * D);
-        matvec<K>(W + wo.Wih, D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f);    // du[e] = sum_g dgi[g] Wih[g][e]
-        matvec<K>(W + wo.Whh, D, 3 * D, D, dgh, 3 * D, ds, D, nullptr, 1.f);    // ds = dgh Whh (dh via recurrent weights)
-        __syncthreads();
-        for (int i = tid; i < KD; i += SA_THREADS) t2[i] += ds[i];
+        matvec<K>(W + wo.Wih, D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f, tiles);    // du[e] = sum_g dgi[g] Wih[g][e]
+        matvec<K>(W + wo.Whh, D, 3 * D, D, dgh, 3 * D, ds, D, nullptr, 1.f, tiles);    // ds = dgh Whh (dh via recurrent weights)
+        for (int i = tid; i < KD; i += nt) t2[i] += ds[i];
         rows_to_global(t1, gr + go.u, go.ld, K, D);
         // ---- u = up Wv^T
         rows_from_global(qp, sv + so.qp, so.ld, K, C);
         rows_from_global(up, sv + so.up, so.ld, K, C);
+        rows_from_global(upn, sv + so.upn, so.ld, K, C);
         if (tid < K) cs[tid] = sv[tid * so.ld + so.csum];
         __syncthreads();
-        matvec64_split<K>(W + wo.Wv, C, D, t1, D, dup, C, 1.f, scr);            // dup[c] = sum_d du[d] Wv[d][c]
+        matvec<K>(W + wo.Wv, C, D, C, t1, D, dup, C, nullptr, 1.f, tiles);             // dup[c] = sum_d du[d] Wv[d][c]
         if (tid < K) {
             float a = 0.f;
             for (int c = 0; c < C; ++c) a += up[tid * C + c] * dup[tid * C + c];
             ud[tid] = a;
         }
+        sa_fold_affine(qp, W + wo.ln_in_g, W + wo.ln_in_b, qg, qb, K);
+        sa_fold_affine(dup, W + wo.ln_in_g, W + wo.ln_in_b, dug, dub, K);
         __syncthreads();
-        // ---- streaming pass: recompute attn, accumulate dq', write / accumulate d LN(x)
+        // ---- streaming pass: recompute attn, accumulate sum dl xn, write / accumulate d xn
         const bool first = (t == p.I - 1), final_ = (t == 0);
-        if (first && final_) sa_stream_bwd<K, true, true>(xb, dxb, N, qp, dup, cs, ud, W + wo.ln_in_g, W + wo.ln_in_b, p.eps, scr, dg_in, db_in);
-        else if (first) sa_stream_bwd<K, true, false>(xb, dxb, N, qp, dup, cs, ud, W + wo.ln_in_g, W + wo.ln_in_b, p.eps, scr, dg_in, db_in);
-        else if (final_) sa_stream_bwd<K, false, true>(xb, dxb, N, qp, dup, cs, ud, W + wo.ln_in_g, W + wo.ln_in_b, p.eps, scr, dg_in, db_in);
-        else sa_stream_bwd<K, false, false>(xb, dxb, N, qp, dup, cs, ud, W + wo.ln_in_g, W + wo.ln_in_b, p.eps, scr, dg_in, db_in);
+        if (first && final_) sa_stream_bwd<K, true, true>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
+        else if (first) sa_stream_bwd<K, true, false>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
+        else if (final_) sa_stream_bwd<K, false, true>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
+        else sa_stream_bwd<K, false, false>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
         __syncthreads();
-        for (int i = tid; i < K * C; i += SA_THREADS) {
+        if (tid < K) {
             float a = 0.f;
-            for (int w = 0; w < SA_WAVES; ++w) a += scr[w * K * C + i];
-            dqp[i] = a;
+            for (int w = 0; w < nw; ++w) a += tiles[(w * K + tid) * (C + 1) + C];
+            sdl[tid] = a;
+        }
+        for (int i = tid; i < K * C; i += nt) {
+            const int j = i >> 6, c = i & 63;
+            float a = 0.f;
+            for (int w = 0; w < nw; ++w) a += tiles[(w * K + j) * (C + 1) + c];
+            dqp[i] = a;                                          // sum_n dl xn (pre-affine)
+        }
+        __syncthreads();
+        // norm_inputs gamma/beta:  d xa = wn dU' + dl q'  =>  dgamma = sum_j dU' upn + q' dqn,  dbeta = sum_j dU' + q' sdl
+        if (tid < C) {
+            float dg = 0.f, db = 0.f;
+            for (int j = 0; j < K; ++j) {
+                dg += dup[j * C + tid] * upn[j * C + tid] + qp[j * C + tid] * dqp[j * C + tid];
+                db += dup[j * C + tid] + qp[j * C + tid] * sdl[j];
+            }
+            dg_in[tid] += dg;
+            db_in[tid] += db;
+        }
+        __syncthreads();
+        for (int i = tid; i < K * C; i += nt) {
+            const int j = i >> 6, c = i & 63;
+            dqp[i] = dqp[i] * W[wo.ln_in_g + c] + W[wo.ln_in_b + c] * sdl[j];   // d q' = sum_n dl LN(x)
         }
         __syncthreads();
         rows_to_global(dqp, gr + go.qp, go.ld, K, C);
         // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
-        matvec<K>(W + wo.WkT, D, C, D, dqp, C, t1, D, nullptr, p.scale);        // t1 = dq
-        __syncthreads();
+        matvec<K>(W + wo.WkT, D, C, D, dqp, C, t1, D, nullptr, p.scale, tiles);        // t1 = dq
         rows_to_global(t1, gr + go.q, go.ld, K, D);
-        matvec<K>(W + wo.Wq, D, D, D, t1, D, ds, D, nullptr, 1.f);              // ds = dsn
+        matvec<K>(W + wo.Wq, D, D, D, t1, D, ds, D, nullptr, 1.f, tiles);              // ds = dsn
+        for (int i = tid; i < KD; i += nt) { t1[i] = ds[i]; ds[i] = t2[i]; }
         __syncthreads();
-        for (int i = tid; i < KD; i += SA_THREADS) { t1[i] = ds[i]; ds[i] = t2[i]; }
-        __syncthreads();
-        ln_rows_bwd(t1, t0, ds, 1, W + wo.ln_s_g, dg_s, db_s, K, D);            // ds = dh + LN_s backward
+        ln_rows_bwd(t1, t0, ds, 1, W + wo.ln_s_g, dg_s, db_s, K, D);                   // ds = dh + LN_s backward
         __syncthreads();
     }
-    for (int i = tid; i < KD; i += SA_THREADS) p.dslots0[(size_t)b * KD + i] = ds[i];
-    for (int i = tid; i < 4 * D + 2 * C; i += SA_THREADS) p.g_small[(size_t)b * (4 * D + 2 * C) + i] = gacc[i];
+    for (int i = tid; i < KD; i += nt) p.dslots0[(size_t)b * KD + i] = ds[i];
+    for (int i = tid; i < 4 * D + 2 * C; i += nt) p.g_small[(size_t)b * (4 * D + 2 * C) + i] = gacc[i];
 }
 
-static size_t sa_fwd_smem(int K, int D, int H) { return (size_t)(K * D * 4 + K * 3 * D * 2 + K * H + K * SA_C * 2 + 16 + 8 * K * (SA_C + 1)) * 4; }
-static size_t sa_bwd_smem(int K, int D, int H) { return (size_t)(K * D * 4 + K * 3 * D * 2 + K * H + K * SA_C * 4 + 32 + 4 * D + 2 * SA_C + 8 * K * SA_C) * 4; }
+static size_t sa_fwd_smem(int K, int D, int H) {
+    const size_t tiles = (size_t)(SA_TF / 64) * 16 * SA_TLD;
+    return (size_t)(K * D * 4 + K * 3 * D * 2 + K * H + K * SA_C * 3 + 32 + tiles) * 4;
+}
+static size_t sa_bwd_smem(int K, int D, int H) {
+    const size_t tiles = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
+    return (size_t)(K * D * 4 + K * 3 * D * 2 + K * H + K * SA_C * 7 + 80 + 4 * D + 2 * SA_C + tiles) * 4;
+}
 
 template <int K>
 static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
     const size_t smem = backward ? sa_bwd_smem(K, a.D, a.H) : sa_fwd_smem(K, a.D, a.H);
     OCRL_REQUIRE(smem <= 160 * 1024, "slot_attn: LDS request %zu too large", smem);
+    // the shared tile region doubles as matvec / reduction scratch: check it is large enough
+    const size_t tiles_f = (size_t)(SA_TF / 64) * 16 * SA_TLD, tiles_b = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
+    const size_t need_f = (size_t)16 * K * (SA_C + 1), need_mv_f = (size_t)(SA_TF / 192) * K * 256, need_mv_b = (size_t)8 * K * 256, need_b = (size_t)(SA_TB / 64) * K * (SA_C + 1);
+    OCRL_REQUIRE(tiles_f >= need_f && tiles_f >= need_mv_f && tiles_b >= need_b && tiles_b >= need_mv_b, "slot_attn: scratch region too small");
     const SaWts wo = sa_wts_layout(a.C, a.D, a.H);
     const SaSave so = sa_save_layout(a.C, a.D, a.H);
     const SaGrad go = sa_grad_layout(a.C, a.D, a.H);
     const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
     if (backward) {
         OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_bwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((slot_attn_bwd_kernel<K>), dim3(a.B), dim3(SA_THREADS), smem, st, a, wo, so, go);
+        hipLaunchKernelGGL((slot_attn_bwd_kernel<K>), dim3(a.B), dim3(SA_TB), smem, st, a, wo, so, go);
     } else {
         OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((slot_attn_fwd_kernel<K>), dim3(a.B), dim3(SA_THREADS), smem, st, a, wo, so);
+        hipLaunchKernelGGL((slot_attn_fwd_kernel<K>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so);
     }
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("slot_attn");
