@@ -466,11 +466,12 @@ __global__ __launch_bounds__(256) void softmax_causal_bwd_kernel(const float* __
     }
 }
 
-// ------------------------------------------------------------------ cross attention to K (<= 8) slots
+// ------------------------------------------------------------------ cross attention to K (<= 16) slots
 // Q [B,T,d] (projected, unscaled), Km/Vm [B,K,d], heads h, dh = d/h (<= 64).  One thread per (b,head,q).
 // P [B,h,T,K] = softmax (pre-dropout) is saved for the backward.
-#define CA_MAXK 8
+// MAXK (8 or 16) is the compile-time slot capacity: per-slot values live in registers.
 #define CA_MAXDH 64
+template <int CA_MAXK>
 __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Km,
                                                              const float* __restrict__ Vm, float* __restrict__ O,
                                                              float* __restrict__ P, int T, int K, int d, int h, float p,
@@ -547,13 +548,14 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
 // backward: dQ [B,T,d] written; dKm/dVm [B,K,d] accumulated with one atomic per (wave, slot, channel)
 // (must be zeroed by the caller).  The per-query outer products are reduced over the 64 queries of a wave
 // through a wave-private LDS staging tile (queries x (K + dh)), not through contended atomics.
-#define CA_SW (CA_MAXK + CA_MAXDH + 1)
+template <int CA_MAXK>
 __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
                                                              const float* __restrict__ Km, const float* __restrict__ Vm,
                                                              const float* __restrict__ P, float* __restrict__ dQ,
                                                              float* __restrict__ dKm, float* __restrict__ dVm, int T, int K, int d,
                                                              int h, float p, unsigned long long seed, unsigned site) {
     extern __shared__ float sm[];   // Ks [K][dh], Vs [K][dh], stage [4][64][CA_SW]
+    constexpr int CA_SW = CA_MAXK + CA_MAXDH + 1;
     const int dh = d / h;
     const int nqb = (T + 255) / 256;
     int bid = blockIdx.x;
@@ -891,25 +893,33 @@ int softmax_causal_bwd_launch(const float* P, float* dPd, long long BH, int T, f
 }
 int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, float* O, float* P, int B, int T, int K, int d, int h, float p,
                           unsigned long long seed, unsigned site, hipStream_t st) {
-    OCRL_REQUIRE(K <= CA_MAXK && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
+    OCRL_REQUIRE(K >= 1 && K <= 16 && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
     const int grid = B * h * cdiv(T, 256);
-    hipLaunchKernelGGL(cross_attn_fwd_kernel, dim3(grid), dim3(256), 2 * K * (d / h) * 4, st, Q, Km, Vm, O, P, T, K, d, h, p, seed, site);
+    if (K <= 8) hipLaunchKernelGGL(cross_attn_fwd_kernel<8>, dim3(grid), dim3(256), 2 * K * (d / h) * 4, st, Q, Km, Vm, O, P, T, K, d, h, p, seed, site);
+    else hipLaunchKernelGGL(cross_attn_fwd_kernel<16>, dim3(grid), dim3(256), 2 * K * (d / h) * 4, st, Q, Km, Vm, O, P, T, K, d, h, p, seed, site);
     OCRL_CHECK_LAUNCH("cross_attn_fwd");
+    return 0;
+}
+template <int MAXK>
+static int cross_attn_bwd_launch_k(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
+                                   int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+    constexpr int SW = MAXK + CA_MAXDH + 1;
+    const int grid = B * h * cdiv(T, 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)cross_attn_bwd_kernel<MAXK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (2 * MAXK * CA_MAXDH + 4 * 64 * SW) * 4));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cross_attn_bwd_kernel<MAXK>, dim3(grid), dim3(256), (2 * K * (d / h) + 4 * 64 * SW) * 4, st, dO, Q, Km, Vm, P, dQ, dKm, dVm, T, K, d, h, p, seed, site);
+    OCRL_CHECK_LAUNCH("cross_attn_bwd");
     return 0;
 }
 int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
                           int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st) {
-    OCRL_REQUIRE(K <= CA_MAXK && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
-    const int grid = B * h * cdiv(T, 256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)cross_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (2 * CA_MAXK * CA_MAXDH + 4 * 64 * CA_SW) * 4));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3(grid), dim3(256), (2 * K * (d / h) + 4 * 64 * CA_SW) * 4, st, dO, Q, Km, Vm, P, dQ, dKm, dVm, T, K, d, h, p, seed, site);
-    OCRL_CHECK_LAUNCH("cross_attn_bwd");
-    return 0;
+    OCRL_REQUIRE(K >= 1 && K <= 16 && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
+    if (K <= 8) return cross_attn_bwd_launch_k<8>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, st);
+    return cross_attn_bwd_launch_k<16>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, st);
 }
 int fill_launch(float* x, long long n, float v, hipStream_t st) {
     hipLaunchKernelGGL(fill_kernel, GRID1D(n), 0, st, x, n, v);

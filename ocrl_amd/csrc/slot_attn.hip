@@ -241,49 +241,59 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
     }
 }
 
+// Slot-side work is independent per slot, so for K > 8 it runs in two blocks of KB = ceil(K/2) slots: the per-block
+// temporaries (LN output, q, GRU gates, MLP hidden) are sized for KB rows and the kernel fits the 160 KB LDS up to K = 16.
+template <int K> struct SaBlk { static constexpr int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB; };
+
 template <int K>
 __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D, H = p.H, N = p.N;
-    constexpr int C = SA_C;
+    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB, KP = SaBlk<K>::KP;
     const int nt = blockDim.x, nw = nt >> 6;
-    float* s = sm;                       // [K][D] slots
-    float* sn = s + K * D;               // [K][D]
-    float* q = sn + K * D;               // [K][D]
-    float* u = q + K * D;                // [K][D]
-    float* gi = u + K * D;               // [K][3D]
-    float* gh = gi + K * 3 * D;          // [K][3D]
-    float* hid = gh + K * 3 * D;         // [K][H]
-    float* qp = hid + K * H;             // [K][C]
-    float* up = qp + K * C;              // [K][C]
-    float* qg = up + K * C;              // [K][C] gamma_in * q'
-    float* cs = qg + K * C;              // [16] weight sums
+    float* s = sm;                       // [KP][D] slots (rows >= K are padding)
+    float* sn = s + KP * D;              // [KB][D]
+    float* q = sn + KB * D;              // [KB][D]
+    float* u = q + KB * D;               // [KB][D]
+    float* gi = u + KB * D;              // [KB][3D]
+    float* gh = gi + KB * 3 * D;         // [KB][3D]
+    float* hid = gh + KB * 3 * D;        // [KB][H]
+    float* qp = hid + KB * H;            // [KP][C]
+    float* up = qp + KP * C;             // [KP][C]
+    float* qg = up + KP * C;             // [KP][C] gamma_in * q'
+    float* cs = qg + KP * C;             // [16] weight sums
     float* qb = cs + 16;                 // [16] beta_in . q'
     float* tiles = qb + 16;              // [waves][16][SA_TLD]: streaming tiles, matvec / reduction scratch
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int KD = K * D;
     const float* W = p.wts;
-    for (int i = tid; i < KD; i += nt) s[i] = p.slots0[(size_t)b * KD + i];
+    for (int i = tid; i < KP * D; i += nt) s[i] = i < K * D ? p.slots0[(size_t)b * K * D + i] : 0.f;
     __syncthreads();
     const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
 
     for (int t = 0; t < p.I; ++t) {
-        float* sv = p.save ? p.save + ((size_t)b * p.I + t) * K * so.ld : nullptr;   // K rows of the save matrix
+        float* sv0 = p.save ? p.save + ((size_t)b * p.I + t) * K * so.ld : nullptr;   // K rows of the save matrix
         // ---- slot side: LN, q, q'
-        if (sv) rows_to_global(s, sv + so.sprev, so.ld, K, D);
-        ln_rows(s, sn, W + wo.ln_s_g, W + wo.ln_s_b, K, D);
-        __syncthreads();
-        matvec<K>(W + wo.WqT, D, D, D, sn, D, q, D, nullptr, 1.f, tiles);
-        matvec<K>(W + wo.Wk, C, D, C, q, D, qp, C, nullptr, p.scale, tiles);
+#pragma unroll 1
+        for (int hb = 0; hb < NB; ++hb) {
+            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+            float* sB = s + j0 * D;
+            float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
+            if (sv) rows_to_global(sB, sv + so.sprev, so.ld, kv, D);
+            ln_rows(sB, sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
+            __syncthreads();
+            matvec<KB>(W + wo.WqT, D, D, D, sn, D, q, D, nullptr, 1.f, tiles);
+            matvec<KB>(W + wo.Wk, C, D, C, q, D, qp + j0 * C, C, nullptr, p.scale, tiles);
+            if (sv) {
+                rows_to_global(sn, sv + so.sn, so.ld, kv, D);
+                rows_to_global(q, sv + so.q, so.ld, kv, D);
+                rows_to_global(qp + j0 * C, sv + so.qp, so.ld, kv, C);
+            }
+            __syncthreads();
+        }
         sa_fold_affine(qp, W + wo.ln_in_g, W + wo.ln_in_b, qg, qb, K);
         __syncthreads();
-        if (sv) {
-            rows_to_global(sn, sv + so.sn, so.ld, K, D);
-            rows_to_global(q, sv + so.q, so.ld, K, D);
-            rows_to_global(qp, sv + so.qp, so.ld, K, C);
-        }
         // ---- streaming pass over the N positions
         sa_stream_fwd<K>(xb, N, qg, qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, tiles, tiles);
         __syncthreads();
@@ -298,46 +308,50 @@ __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, Sa
             float a = 0.f;
             for (int w = 0; w < nw; ++w) a += tiles[(w * K + j) * (C + 1) + c];
             a /= cs[j];                                                  // sum_n w xn / sum_n w
-            up[i] = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
-            if (sv) sv[j * so.ld + so.upn + c] = a;
+            const float v = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
+            up[i] = v;
+            if (sv0) { sv0[j * so.ld + so.upn + c] = a; sv0[j * so.ld + so.up + c] = v; }
         }
+        if (sv0 && tid < K) sv0[tid * so.ld + so.csum] = cs[tid];
         __syncthreads();
-        if (sv) {
-            rows_to_global(up, sv + so.up, so.ld, K, C);
-            if (tid < K) sv[tid * so.ld + so.csum] = cs[tid];
-        }
         // ---- updates = U' Wv^T ; GRU ; residual MLP
-        matvec<K>(W + wo.WvT, D, C, D, up, C, u, D, nullptr, 1.f, tiles);
-        matvec<K>(W + wo.WihT, 3 * D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f, tiles);
-        matvec<K>(W + wo.WhhT, 3 * D, D, 3 * D, s, D, gh, 3 * D, W + wo.bhh, 1.f, tiles);
-        for (int i = tid; i < KD; i += nt) {
-            const int j = i / D, c = i - j * D;
-            const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
-            const float z = sigmoidf_(gi[j * 3 * D + D + c] + gh[j * 3 * D + D + c]);
-            const float hn = gh[j * 3 * D + 2 * D + c];
-            const float nn = tanhf(gi[j * 3 * D + 2 * D + c] + r * hn);
-            const float sg = (1.f - z) * nn + z * s[i];
-            if (sv) {
-                float* row = sv + j * so.ld + c;
-                row[so.u] = u[i]; row[so.r] = r; row[so.z] = z; row[so.n] = nn; row[so.hn] = hn; row[so.sg] = sg;
+#pragma unroll 1
+        for (int hb = 0; hb < NB; ++hb) {
+            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+            float* sB = s + j0 * D;
+            float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
+            matvec<KB>(W + wo.WvT, D, C, D, up + j0 * C, C, u, D, nullptr, 1.f, tiles);
+            matvec<KB>(W + wo.WihT, 3 * D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f, tiles);
+            matvec<KB>(W + wo.WhhT, 3 * D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f, tiles);
+            for (int i = tid; i < KB * D; i += nt) {
+                const int j = i / D, c = i - j * D;
+                const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
+                const float z = sigmoidf_(gi[j * 3 * D + D + c] + gh[j * 3 * D + D + c]);
+                const float hn = gh[j * 3 * D + 2 * D + c];
+                const float nn = tanhf(gi[j * 3 * D + 2 * D + c] + r * hn);
+                const float sg = (1.f - z) * nn + z * sB[i];
+                if (sv && j < kv) {
+                    float* row = sv + j * so.ld + c;
+                    row[so.u] = u[i]; row[so.r] = r; row[so.z] = z; row[so.n] = nn; row[so.hn] = hn; row[so.sg] = sg;
+                }
+                q[i] = sg;      // q is free now: holds s_gru
             }
-            q[i] = sg;      // q is free now: holds s_gru
+            __syncthreads();
+            ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, KB, D);      // sn = m
+            __syncthreads();
+            matvec<KB>(W + wo.W0T, H, D, H, sn, D, hid, H, W + wo.b0, 1.f, tiles);
+            for (int i = tid; i < KB * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
+            __syncthreads();
+            matvec<KB>(W + wo.W2T, D, H, D, hid, H, u, D, W + wo.b2, 1.f, tiles);      // u = mlp out
+            for (int i = tid; i < kv * D; i += nt) sB[i] = q[i] + u[i];
+            if (sv) {
+                rows_to_global(sn, sv + so.m, so.ld, kv, D);
+                rows_to_global(hid, sv + so.hid, so.ld, kv, H);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, K, D);      // sn = m
-        __syncthreads();
-        matvec<K>(W + wo.W0T, H, D, H, sn, D, hid, H, W + wo.b0, 1.f, tiles);
-        for (int i = tid; i < K * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
-        __syncthreads();
-        matvec<K>(W + wo.W2T, D, H, D, hid, H, u, D, W + wo.b2, 1.f, tiles);      // u = mlp out
-        for (int i = tid; i < KD; i += nt) s[i] = q[i] + u[i];
-        if (sv) {
-            rows_to_global(sn, sv + so.m, so.ld, K, D);
-            rows_to_global(hid, sv + so.hid, so.ld, K, H);
-        }
-        __syncthreads();
     }
-    for (int i = tid; i < KD; i += nt) p.slots[(size_t)b * KD + i] = s[i];
+    for (int i = tid; i < K * D; i += nt) p.slots[(size_t)b * K * D + i] = s[i];
 }
 
 // ------------------------------------------------------------------------------------------- backward streaming pass
@@ -360,9 +374,10 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
         dur[k] = li < K ? dug[li * SA_C + ch] : 0.f;
     }
     // B operands of d xn[pos][ch] = sum_slot (wn[pos][slot] dug[slot][ch] + dl[pos][slot] qg[slot][ch]), slot = 4s + g
-    float duB[2][4], qpB[2][4];
+    constexpr int NS = (K + 3) / 4;
+    float duB[NS][4], qpB[NS][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int slot = 4 * s + g;
@@ -415,7 +430,7 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
 #pragma unroll
         for (int m = 0; m < 4; ++m) Dx[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const float wa = wt0[li * SA_WLD + 4 * s + g], da2 = wt1[li * SA_WLD + 4 * s + g];     // A layout: [pos li][slot 4s+g]
 #pragma unroll
             for (int m = 0; m < 4; ++m) { Dx[m] = MFMA16(wa, duB[s][m], Dx[m]); Dx[m] = MFMA16(da2, qpB[s][m], Dx[m]); }
@@ -472,23 +487,21 @@ template <int K>
 __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, SaGrad go) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D, H = p.H, N = p.N;
-    constexpr int C = SA_C;
+    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB, KP = SaBlk<K>::KP;
     const int nt = blockDim.x, nw = nt >> 6;
-    float* ds = sm;                      // [K][D] gradient wrt the iteration output
-    float* t0 = ds + K * D;              // [K][D] scratch
-    float* t1 = t0 + K * D;              // [K][D] scratch
-    float* t2 = t1 + K * D;              // [K][D] scratch
-    float* dgi = t2 + K * D;             // [K][3D]
-    float* dgh = dgi + K * 3 * D;        // [K][3D]
-    float* dhid = dgh + K * 3 * D;       // [K][H]
-    float* qp = dhid + K * H;            // [K][C]
-    float* up = qp + K * C;              // [K][C]
-    float* dup = up + K * C;             // [K][C]
-    float* dqp = dup + K * C;            // [K][C]
-    float* qg = dqp + K * C;             // [K][C] gamma_in * q'
-    float* dug = qg + K * C;             // [K][C] gamma_in * dU'
-    float* upn = dug + K * C;            // [K][C] pre-affine U'
-    float* cs = upn + K * C;             // [16] csum
+    float* ds = sm;                      // [KP][D] gradient wrt the iteration output
+    float* t2 = ds + KP * D;             // [KP][D] dh (direct GRU path), kept across the streaming pass
+    float* t0 = t2 + KP * D;             // [KB][D] scratch
+    float* t1 = t0 + KB * D;             // [KB][D] scratch
+    float* dgi = t1 + KB * D;            // [KB][3D]
+    float* dgh = dgi + KB * 3 * D;       // [KB][3D]
+    float* dhid = dgh + KB * 3 * D;      // [KB][H]
+    float* qp = dhid + KB * H;           // [KP][C]
+    float* dup = qp + KP * C;            // [KP][C]
+    float* dqp = dup + KP * C;           // [KP][C]
+    float* qg = dqp + KP * C;            // [KP][C] gamma_in * q'
+    float* dug = qg + KP * C;            // [KP][C] gamma_in * dU'
+    float* cs = dug + KP * C;            // [16] csum
     float* ud = cs + 16;                 // [16] up . dup
     float* qb = ud + 16;                 // [16] beta_in . q'
     float* dub = qb + 16;                // [16] beta_in . dU'
@@ -498,9 +511,8 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int KD = K * D;
     const float* W = p.wts;
-    for (int i = tid; i < KD; i += nt) ds[i] = p.dslots[(size_t)b * KD + i];
+    for (int i = tid; i < KP * D; i += nt) ds[i] = i < K * D ? p.dslots[(size_t)b * K * D + i] : 0.f;
     for (int i = tid; i < 4 * D + 2 * C; i += nt) gacc[i] = 0.f;
     __syncthreads();
     float* dg_s = gacc;  float* db_s = gacc + D;
@@ -510,55 +522,60 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
     float4* dxb = reinterpret_cast<float4*>(p.dx + (size_t)b * N * C);
 
     for (int t = p.I - 1; t >= 0; --t) {
-        const float* sv = p.save + ((size_t)b * p.I + t) * K * so.ld;
-        float* gr = p.grows + ((size_t)b * p.I + t) * K * go.ld;
-        // ---- residual MLP backward: s_new = sg + W2 relu(W0 m + b0) + b2,  m = LN_m(sg)
-        rows_to_global(ds, gr + go.out, go.ld, K, D);
-        rows_from_global(t0, sv + so.sg, so.ld, K, D);
-        matvec<K>(W + wo.W2, H, D, H, ds, D, dhid, H, nullptr, 1.f, tiles);            // dhid[h] = sum_d ds[d] W2[d][h]
-        for (int i = tid; i < K * H; i += nt) {
-            const int j = i / H, c = i - j * H;
-            const float v = sv[j * so.ld + so.hid + c] > 0.f ? dhid[i] : 0.f;
-            dhid[i] = v;
-            gr[j * go.ld + go.hid + c] = v;
+        const float* sv0 = p.save + ((size_t)b * p.I + t) * K * so.ld;
+        float* gr0 = p.grows + ((size_t)b * p.I + t) * K * go.ld;
+#pragma unroll 1
+        for (int hb = 0; hb < NB; ++hb) {
+            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+            const float* sv = sv0 + (size_t)j0 * so.ld;
+            float* gr = gr0 + (size_t)j0 * go.ld;
+            float* dsB = ds + j0 * D;
+            float* t2B = t2 + j0 * D;
+            // ---- residual MLP backward: s_new = sg + W2 relu(W0 m + b0) + b2,  m = LN_m(sg)
+            rows_to_global(dsB, gr + go.out, go.ld, kv, D);
+            rows_from_global(t0, sv + so.sg, so.ld, kv, D);
+            matvec<KB>(W + wo.W2, H, D, H, dsB, D, dhid, H, nullptr, 1.f, tiles);          // dhid[h] = sum_d ds[d] W2[d][h]
+            for (int i = tid; i < kv * H; i += nt) {
+                const int j = i / H, c = i - j * H;
+                const float v = sv[j * so.ld + so.hid + c] > 0.f ? dhid[i] : 0.f;
+                dhid[i] = v;
+                gr[j * go.ld + go.hid + c] = v;
+            }
+            __syncthreads();
+            matvec<KB>(W + wo.W0, D, H, D, dhid, H, t1, D, nullptr, 1.f, tiles);           // dm[e] = sum_h dhid[h] W0[h][e]
+            ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_m_g, dg_m, db_m, kv, D);                 // ds = d s_gru
+            __syncthreads();
+            // ---- GRU backward
+            for (int i = tid; i < kv * D; i += nt) {
+                const int j = i / D, c = i - j * D;
+                const float* row = sv + j * so.ld + c;
+                const float r = row[so.r], z = row[so.z], nn = row[so.n], hn = row[so.hn], h = row[so.sprev];
+                const float gg = dsB[i];
+                const float dn_pre = gg * (1.f - z) * (1.f - nn * nn);
+                const float dz_pre = gg * (h - nn) * z * (1.f - z);
+                const float dr_pre = dn_pre * hn * r * (1.f - r);
+                dgi[j * 3 * D + c] = dr_pre; dgi[j * 3 * D + D + c] = dz_pre; dgi[j * 3 * D + 2 * D + c] = dn_pre;
+                dgh[j * 3 * D + c] = dr_pre; dgh[j * 3 * D + D + c] = dz_pre; dgh[j * 3 * D + 2 * D + c] = dn_pre * r;
+                t2B[i] = gg * z;               // dh (direct path)
+            }
+            __syncthreads();
+            rows_to_global(dgi, gr + go.gi, go.ld, kv, 3 * D);
+            rows_to_global(dgh, gr + go.gh, go.ld, kv, 3 * D);
+            matvec<KB>(W + wo.Wih, D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f, tiles);   // du[e] = sum_g dgi[g] Wih[g][e]
+            matvec<KB>(W + wo.Whh, D, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f, tiles);   // dh via the recurrent weights
+            for (int i = tid; i < kv * D; i += nt) t2B[i] += t0[i];
+            rows_to_global(t1, gr + go.u, go.ld, kv, D);
+            // ---- u = up Wv^T
+            matvec<KB>(W + wo.Wv, C, D, C, t1, D, dup + j0 * C, C, nullptr, 1.f, tiles);   // dup[c] = sum_d du[d] Wv[d][c]
         }
-        __syncthreads();
-        matvec<K>(W + wo.W0, D, H, D, dhid, H, t1, D, nullptr, 1.f, tiles);            // dm[e] = sum_h dhid[h] W0[h][e]
-        ln_rows_bwd(t1, t0, ds, 1, W + wo.ln_m_g, dg_m, db_m, K, D);                   // ds = d s_gru
-        __syncthreads();
-        // ---- GRU backward
-        for (int i = tid; i < KD; i += nt) {
-            const int j = i / D, c = i - j * D;
-            const float* row = sv + j * so.ld + c;
-            const float r = row[so.r], z = row[so.z], nn = row[so.n], hn = row[so.hn], h = row[so.sprev];
-            const float gg = ds[i];
-            const float dn_pre = gg * (1.f - z) * (1.f - nn * nn);
-            const float dz_pre = gg * (h - nn) * z * (1.f - z);
-            const float dr_pre = dn_pre * hn * r * (1.f - r);
-            dgi[j * 3 * D + c] = dr_pre; dgi[j * 3 * D + D + c] = dz_pre; dgi[j * 3 * D + 2 * D + c] = dn_pre;
-            dgh[j * 3 * D + c] = dr_pre; dgh[j * 3 * D + D + c] = dz_pre; dgh[j * 3 * D + 2 * D + c] = dn_pre * r;
-            t2[i] = gg * z;                // dh (direct path)
-            t0[i] = h;                     // s_prev, for LN_s backward below
-        }
-        __syncthreads();
-        rows_to_global(dgi, gr + go.gi, go.ld, K, 3 * D);
-        rows_to_global(dgh, gr + go.gh, go.ld, K, 3 * D);
-        matvec<K>(W + wo.Wih, D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f, tiles);    // du[e] = sum_g dgi[g] Wih[g][e]
-        matvec<K>(W + wo.Whh, D, 3 * D, D, dgh, 3 * D, ds, D, nullptr, 1.f, tiles);    // ds = dgh Whh (dh via recurrent weights)
-        for (int i = tid; i < KD; i += nt) t2[i] += ds[i];
-        rows_to_global(t1, gr + go.u, go.ld, K, D);
-        // ---- u = up Wv^T
-        rows_from_global(qp, sv + so.qp, so.ld, K, C);
-        rows_from_global(up, sv + so.up, so.ld, K, C);
-        rows_from_global(upn, sv + so.upn, so.ld, K, C);
-        if (tid < K) cs[tid] = sv[tid * so.ld + so.csum];
-        __syncthreads();
-        matvec<K>(W + wo.Wv, C, D, C, t1, D, dup, C, nullptr, 1.f, tiles);             // dup[c] = sum_d du[d] Wv[d][c]
+        rows_from_global(qp, sv0 + so.qp, so.ld, K, C);
         if (tid < K) {
+            cs[tid] = sv0[tid * so.ld + so.csum];
             float a = 0.f;
-            for (int c = 0; c < C; ++c) a += up[tid * C + c] * dup[tid * C + c];
+            for (int c = 0; c < C; ++c) a += sv0[tid * so.ld + so.up + c] * dup[tid * C + c];
             ud[tid] = a;
         }
+        __syncthreads();
         sa_fold_affine(qp, W + wo.ln_in_g, W + wo.ln_in_b, qg, qb, K);
         sa_fold_affine(dup, W + wo.ln_in_g, W + wo.ln_in_b, dug, dub, K);
         __syncthreads();
@@ -585,7 +602,7 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
         if (tid < C) {
             float dg = 0.f, db = 0.f;
             for (int j = 0; j < K; ++j) {
-                dg += dup[j * C + tid] * upn[j * C + tid] + qp[j * C + tid] * dqp[j * C + tid];
+                dg += dup[j * C + tid] * sv0[j * so.ld + so.upn + tid] + qp[j * C + tid] * dqp[j * C + tid];
                 db += dup[j * C + tid] + qp[j * C + tid] * sdl[j];
             }
             dg_in[tid] += dg;
@@ -597,37 +614,50 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
             dqp[i] = dqp[i] * W[wo.ln_in_g + c] + W[wo.ln_in_b + c] * sdl[j];   // d q' = sum_n dl LN(x)
         }
         __syncthreads();
-        rows_to_global(dqp, gr + go.qp, go.ld, K, C);
-        // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
-        matvec<K>(W + wo.WkT, D, C, D, dqp, C, t1, D, nullptr, p.scale, tiles);        // t1 = dq
-        rows_to_global(t1, gr + go.q, go.ld, K, D);
-        matvec<K>(W + wo.Wq, D, D, D, t1, D, ds, D, nullptr, 1.f, tiles);              // ds = dsn
-        for (int i = tid; i < KD; i += nt) { t1[i] = ds[i]; ds[i] = t2[i]; }
-        __syncthreads();
-        ln_rows_bwd(t1, t0, ds, 1, W + wo.ln_s_g, dg_s, db_s, K, D);                   // ds = dh + LN_s backward
-        __syncthreads();
+        rows_to_global(dqp, gr0 + go.qp, go.ld, K, C);
+#pragma unroll 1
+        for (int hb = 0; hb < NB; ++hb) {
+            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+            const float* sv = sv0 + (size_t)j0 * so.ld;
+            float* gr = gr0 + (size_t)j0 * go.ld;
+            float* dsB = ds + j0 * D;
+            // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
+            matvec<KB>(W + wo.WkT, D, C, D, dqp + j0 * C, C, t1, D, nullptr, p.scale, tiles);   // t1 = dq
+            rows_to_global(t1, gr + go.q, go.ld, kv, D);
+            rows_from_global(t0, sv + so.sprev, so.ld, kv, D);
+            matvec<KB>(W + wo.Wq, D, D, D, t1, D, dsB, D, nullptr, 1.f, tiles);                 // ds = dsn
+            for (int i = tid; i < kv * D; i += nt) { t1[i] = dsB[i]; dsB[i] = t2[j0 * D + i]; }
+            __syncthreads();
+            ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_s_g, dg_s, db_s, kv, D);                      // ds = dh + LN_s backward
+            __syncthreads();
+        }
     }
-    for (int i = tid; i < KD; i += nt) p.dslots0[(size_t)b * KD + i] = ds[i];
+    for (int i = tid; i < K * D; i += nt) p.dslots0[(size_t)b * K * D + i] = ds[i];
     for (int i = tid; i < 4 * D + 2 * C; i += nt) p.g_small[(size_t)b * (4 * D + 2 * C) + i] = gacc[i];
 }
 
 static size_t sa_fwd_smem(int K, int D, int H) {
+    const int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB;
     const size_t tiles = (size_t)(SA_TF / 64) * 16 * SA_TLD;
-    return (size_t)(K * D * 4 + K * 3 * D * 2 + K * H + K * SA_C * 3 + 32 + tiles) * 4;
+    return (size_t)(KP * D + KB * D * 3 + KB * 3 * D * 2 + KB * H + KP * SA_C * 3 + 32 + tiles) * 4;
 }
 static size_t sa_bwd_smem(int K, int D, int H) {
+    const int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB;
     const size_t tiles = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
-    return (size_t)(K * D * 4 + K * 3 * D * 2 + K * H + K * SA_C * 7 + 80 + 4 * D + 2 * SA_C + tiles) * 4;
+    return (size_t)(KP * D * 2 + KB * D * 2 + KB * 3 * D * 2 + KB * H + KP * SA_C * 5 + 80 + 4 * D + 2 * SA_C + tiles) * 4;
 }
 
 template <int K>
 static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
     const size_t smem = backward ? sa_bwd_smem(K, a.D, a.H) : sa_fwd_smem(K, a.D, a.H);
-    OCRL_REQUIRE(smem <= 160 * 1024, "slot_attn: LDS request %zu too large", smem);
+    OCRL_REQUIRE(smem <= 160 * 1024, "slot_attn: LDS request %zu too large (num_slots %d, slot size %d)", smem, K, a.D);
     // the shared tile region doubles as matvec / reduction scratch: check it is large enough
+    constexpr int KB = SaBlk<K>::KB;
     const size_t tiles_f = (size_t)(SA_TF / 64) * 16 * SA_TLD, tiles_b = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
-    const size_t need_f = (size_t)16 * K * (SA_C + 1), need_mv_f = (size_t)(SA_TF / 192) * K * 256, need_mv_b = (size_t)8 * K * 256, need_b = (size_t)(SA_TB / 64) * K * (SA_C + 1);
-    OCRL_REQUIRE(tiles_f >= need_f && tiles_f >= need_mv_f && tiles_b >= need_b && tiles_b >= need_mv_b, "slot_attn: scratch region too small");
+    const size_t part_f = (size_t)(SA_TF / 64) * K * (SA_C + 1), part_b = (size_t)(SA_TB / 64) * K * (SA_C + 1);
+    const size_t mv_f = (size_t)16 * KB * 64 > (size_t)(SA_TF / 64) * KB * 64 ? (size_t)16 * KB * 64 : (size_t)(SA_TF / 64) * KB * 64;   // G * KB * NC <= threads * KB
+    const size_t mv_b = (size_t)(SA_TB / 64) * KB * 64;
+    OCRL_REQUIRE(tiles_f >= part_f && tiles_f >= mv_f && tiles_b >= part_b && tiles_b >= mv_b, "slot_attn: scratch region too small");
     const SaWts wo = sa_wts_layout(a.C, a.D, a.H);
     const SaSave so = sa_save_layout(a.C, a.D, a.H);
     const SaGrad go = sa_grad_layout(a.C, a.D, a.H);
@@ -646,7 +676,7 @@ static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
 
 int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st) {
     OCRL_REQUIRE(a.C == SA_C, "slot_attn: input width must be %d (got %d)", SA_C, a.C);
-    OCRL_REQUIRE(a.K >= 1 && a.K <= 8, "slot_attn: 1 <= num_slots <= 8 supported (got %d)", a.K);
+    OCRL_REQUIRE(a.K >= 1 && a.K <= 16, "slot_attn: 1 <= num_slots <= 16 supported (got %d)", a.K);
     OCRL_REQUIRE(a.D % 64 == 0 && a.H % 64 == 0 && a.D <= 256 && a.H <= 256, "slot_attn: slot/mlp size must be multiples of 64, <= 256");
     OCRL_REQUIRE(a.B > 0 && a.N > 0 && a.I >= 1, "slot_attn: empty problem");
     OCRL_REQUIRE((long long)a.N * 16 < (1ll << 31), "slot_attn: N too large for 32-bit row offsets");
@@ -654,15 +684,12 @@ int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st) {
     if (backward) OCRL_REQUIRE(a.dx && ((uintptr_t)a.dx & 15) == 0 && a.save && a.grows && a.dslots && a.dslots0 && a.g_small, "slot_attn bwd: missing buffers");
     else OCRL_REQUIRE(a.slots0 && a.slots, "slot_attn fwd: missing buffers");
     switch (a.K) {
-        case 1: return sa_launch_k<1>(a, backward, st);
-        case 2: return sa_launch_k<2>(a, backward, st);
-        case 3: return sa_launch_k<3>(a, backward, st);
-        case 4: return sa_launch_k<4>(a, backward, st);
-        case 5: return sa_launch_k<5>(a, backward, st);
-        case 6: return sa_launch_k<6>(a, backward, st);
-        case 7: return sa_launch_k<7>(a, backward, st);
-        default: return sa_launch_k<8>(a, backward, st);
+#define SA_CASE(k) case k: return sa_launch_k<k>(a, backward, st);
+        SA_CASE(1) SA_CASE(2) SA_CASE(3) SA_CASE(4) SA_CASE(5) SA_CASE(6) SA_CASE(7) SA_CASE(8)
+        SA_CASE(9) SA_CASE(10) SA_CASE(11) SA_CASE(12) SA_CASE(13) SA_CASE(14) SA_CASE(15) SA_CASE(16)
+#undef SA_CASE
     }
+    return -1;
 }
 
 // ------------------------------------------------------------------------------------------- packing

@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 SMALL = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2)
 MID = dict(obs_size=32, vocab_size=512, num_slots=5, num_iterations=2, num_dec_blocks=2)
 LONG = dict(obs_size=64, vocab_size=256, num_slots=4, num_iterations=1, num_dec_blocks=1)     # T = 256: four causal key tiles
+K16 = dict(obs_size=16, vocab_size=256, num_slots=16, num_iterations=2, num_dec_blocks=1)     # BASELINE config 5's slot count (two slot blocks)
+K11 = dict(obs_size=16, vocab_size=256, num_slots=11, num_iterations=2, num_dec_blocks=1)     # uneven slot blocks (6 + 5)
 
 
 def make_engine(cfg, B):
@@ -78,7 +80,7 @@ def compare_grads(tag, eng, trainer):
     return worst, rows
 
 
-@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2)])
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2)])
 def test_forward_backward_eval(tag, over, B):
     """dropout off: every stage of the forward, then every parameter gradient"""
     cfg = O.default_cfg(**over)
