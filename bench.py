@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak
-FWD_FLOP_PER_IMAGE = {128: 22384148480, 64: 5004001280}     # SURVEY.md §8(d), 6 slots / 3 iters
+FWD_FLOP_PER_IMAGE = {(128, 6): 22384148480, (64, 6): 5004001280, (256, 16): 129805844480}     # (S, slots), 3 iters
 
 
 def slate_config(obs_size, num_slots=6, num_iterations=3):
@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--obs-size", type=int, default=128)
+    ap.add_argument("--num-slots", type=int, default=6, help="6 = headline; 16 with --obs-size 256 = BASELINE config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["slate", "slotattn"], default="slate", help="slotattn = BASELINE config 2 (use_bcdec); headline = slate")
     ap.add_argument("--dropout", type=float, default=0.1, help="diagnostic only: the headline number uses the reference default 0.1")
@@ -92,7 +93,7 @@ def main():
     from ocrl_amd import _lib, ocrs
     from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
     S, B = args.obs_size, args.batch
-    ocr, env = slate_config(S)
+    ocr, env = slate_config(S, num_slots=args.num_slots)
     ocr.learning.dropout = args.dropout
     ocr.use_bcdec = args.workload == "slotattn"
     torch.manual_seed(0)                       # identical initial weights on every rank
@@ -147,19 +148,19 @@ def main():
     except Exception:
         pass
     out = {
-        "metric": "images/sec (node) SLATE pretrain 128x128, 6 slots, 3 iters" if args.workload == "slate" else
-                  "images/sec (node) Slot-Attention (use_bcdec) pretrain 128x128, 6 slots, 3 iters",
+        "metric": f"images/sec (node) SLATE pretrain {S}x{S}, {args.num_slots} slots, 3 iters" if args.workload == "slate" else
+                  f"images/sec (node) Slot-Attention (use_bcdec) pretrain {S}x{S}, {args.num_slots} slots, 3 iters",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SLATE {S}x{S}, 6 slots, 3 iters, vocab 4096, d_model 192, 4 decoder blocks; full update() step "
+        "config": {"workload": f"SLATE {S}x{S}, {args.num_slots} slots, 3 iters, vocab 4096, d_model 192, 4 decoder blocks; full update() step "
                                f"(fwd+bwd+all-reduce+inf-norm clip+Adam), train mode dropout 0.1, device RNG; random-N5C4S4S2-style scenes",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<5,64,64> (CNN encoder 5x5 conv, fwd + bwd-data launches)",
                      "achieved": round(conv_tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(conv_tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
                      "launches": int(cnt[0]), "avg_ms": round(conv_ms, 4)},
-        "step_mfma_frac": round(ips / world * 3 * FWD_FLOP_PER_IMAGE.get(S, 0) / (PEAK_MFMA_F32_TFLOPS * 1e12), 4),
+        "step_mfma_frac": round(ips / world * 3 * FWD_FLOP_PER_IMAGE.get((S, args.num_slots), 0) / (PEAK_MFMA_F32_TFLOPS * 1e12), 4),
         "final_loss": round(loss, 4),
     }
     if args.workload != "slate":
