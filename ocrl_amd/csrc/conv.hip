@@ -35,19 +35,27 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
     const int b = bid;
     const int x0 = tx * TW, y0 = ty * TH;
 
-    // ---- halo tile -> LDS (zero outside the image)
+    // ---- halo tile -> LDS (zero outside the image): all global loads are issued before the first LDS store
     {
         constexpr int F4 = CIN / 4;
         constexpr int TOTAL = HH_ * HW_ * F4;
+        constexpr int NLD = (TOTAL + 255) / 256;
         const float* Xb = p.X + (size_t)b * p.H * p.W * CIN;
-        for (int idx = threadIdx.x; idx < TOTAL; idx += 256) {
+        float4 hv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256;
             const int c4 = idx % F4, hp = idx / F4;
             const int hx = hp % HW_, hy = hp / HW_;
             const int y = y0 - P + hy, x = x0 - P + hx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-                v = *reinterpret_cast<const float4*>(Xb + ((size_t)y * p.W + x) * CIN + c4 * 4);
-            *reinterpret_cast<float4*>(smem + hp * LDH + c4 * 4) = v;
+            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOTAL && y >= 0 && y < p.H && x >= 0 && x < p.W)
+                hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * p.W + x) * CIN + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            if (idx < TOTAL) *reinterpret_cast<float4*>(smem + (idx / F4) * LDH + (idx % F4) * 4) = hv[i];
         }
     }
     __syncthreads();
@@ -60,30 +68,72 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
 
     const float* wl = p.Wp + li * 8 + 4 * lh;   // lane's slice inside one [COUT][8] block
     constexpr int NIT = KS * KS * NCH;
-    float4 nb0 = *reinterpret_cast<const float4*>(wl);
-    float4 nb1 = *reinterpret_cast<const float4*>(wl + 32 * 8);
-#pragma unroll 1
-    for (int tap = 0; tap < KS * KS; ++tap) {
-        const int ky = tap / KS, kx = tap % KS;
-        const float* arow = smem + ((wave + ky) * HW_ + li + kx) * LDH + 4 * lh;
+    if constexpr (NCH >= 4) {
+        // Operand ring of one tap (NCH slots): slot cc holds A (LDS) and B (packed weights, L2) of k-chunk cc; right after
+        // its 8 MFMAs are issued the slot is refilled with the NEXT tap's chunk cc, i.e. NCH-1 chunks (>= 1.5k MFMA
+        // cycles) ahead of its use, so neither the L2 nor the LDS latency is exposed.
+        float4 ra[NCH], rb0[NCH], rb1[NCH];
+        {
+            const float* arow = smem + (wave * HW_ + li) * LDH + 4 * lh;
 #pragma unroll
-        for (int cc = 0; cc < NCH; ++cc) {
-            const int it = tap * NCH + cc;
-            const float4 b0 = nb0, b1 = nb1;
-            if (it + 1 < NIT) {
-                const size_t wo = p.diag ? 0 : (size_t)(it + 1) * COUT * 8;
-                nb0 = *reinterpret_cast<const float4*>(wl + wo);
-                nb1 = *reinterpret_cast<const float4*>(wl + wo + 32 * 8);
+            for (int cc = 0; cc < NCH; ++cc) {
+                rb0[cc] = *reinterpret_cast<const float4*>(wl + (size_t)cc * COUT * 8);
+                rb1[cc] = *reinterpret_cast<const float4*>(wl + (size_t)cc * COUT * 8 + 32 * 8);
+                ra[cc] = *reinterpret_cast<const float4*>(arow + cc * 8);
+                __builtin_amdgcn_sched_barrier(0);      // keep the ring's issue order: the loop's s_waitcnt counts rely on it
             }
-            const float4 a = *reinterpret_cast<const float4*>(arow + cc * 8);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int tn = tap + 1;
+            const bool more = tn < KS * KS;
+            const int ky = tn / KS, kx = tn - ky * KS;
+            const float* arow = smem + ((wave + (more ? ky : 0)) * HW_ + li + (more ? kx : 0)) * LDH + 4 * lh;
+            const float* wn = wl + ((p.diag || !more) ? 0 : (size_t)tn * NCH * COUT * 8);
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) {
+                const float4 a = ra[cc], b0 = rb0[cc], b1 = rb1[cc];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                // (after the last tap this harmlessly re-reads tap 0: no branch in the loop body)
+                rb0[cc] = *reinterpret_cast<const float4*>(wn + (size_t)cc * COUT * 8);
+                rb1[cc] = *reinterpret_cast<const float4*>(wn + (size_t)cc * COUT * 8 + 32 * 8);
+                ra[cc] = *reinterpret_cast<const float4*>(arow + cc * 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        float4 nb0 = *reinterpret_cast<const float4*>(wl);
+        float4 nb1 = *reinterpret_cast<const float4*>(wl + 32 * 8);
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            const float* arow = smem + ((wave + ky) * HW_ + li + kx) * LDH + 4 * lh;
+#pragma unroll
+            for (int cc = 0; cc < NCH; ++cc) {
+                const int it = tap * NCH + cc;
+                const float4 b0 = nb0, b1 = nb1;
+                if (it + 1 < NIT) {
+                    const size_t wo = p.diag ? 0 : (size_t)(it + 1) * COUT * 8;
+                    nb0 = *reinterpret_cast<const float4*>(wl + wo);
+                    nb1 = *reinterpret_cast<const float4*>(wl + wo + 32 * 8);
+                }
+                const float4 a = *reinterpret_cast<const float4*>(arow + cc * 8);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            }
         }
     }
 
@@ -136,36 +186,51 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // global -> register staging of one tile (dY tile + X rows shifted by this workgroup's ky): the loads of tile t+1
+    // are in flight while tile t's MFMAs run; the registers are written to LDS after the barrier that retires tile t.
+    constexpr int FY = COUT / 4, FX = CIN / 4;
+    constexpr int NDY = (TH * TW * FY + 255) / 256, XT = TH * HW_ * FX, NX = (XT + 255) / 256;
+    float4 rdy[NDY], rx[NX];
+    auto gload = [&](int t) {
         int q = t;
         const int tx = q % tiles_x; q /= tiles_x;
         const int ty = q % tiles_y; q /= tiles_y;
         const int b = q;
         const int x0 = tx * TW, y0 = ty * TH;
-        __syncthreads();   // previous tile fully consumed
-        {   // dY tile
-            constexpr int F4 = COUT / 4;
-            const float* g = p.dY + (size_t)b * p.H * p.W * COUT;
-            for (int idx = threadIdx.x; idx < TH * TW * F4; idx += 256) {
-                const int c4 = idx % F4, pp = idx / F4;
-                const int x = x0 + (pp % TW), y = y0 + (pp / TW);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (y < p.H && x < p.W) v = *reinterpret_cast<const float4*>(g + ((size_t)y * p.W + x) * COUT + c4 * 4);
-                *reinterpret_cast<float4*>(dYs + pp * COUT + c4 * 4) = v;
-            }
+        const float* gy = p.dY + (size_t)b * p.H * p.W * COUT;
+        const float* gx = p.X + (size_t)b * p.H * p.W * CIN;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int c4 = idx % FY, pp = idx / FY;
+            const int x = x0 + (pp % TW), y = y0 + (pp / TW);
+            rdy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < p.H && x < p.W) rdy[i] = *reinterpret_cast<const float4*>(gy + ((size_t)y * p.W + x) * COUT + c4 * 4);
         }
-        {   // X rows shifted by this workgroup's ky
-            constexpr int F4 = CIN / 4;
-            const float* g = p.X + (size_t)b * p.H * p.W * CIN;
-            for (int idx = threadIdx.x; idx < TH * HW_ * F4; idx += 256) {
-                const int c4 = idx % F4, hp = idx / F4;
-                const int x = x0 - P + (hp % HW_), y = y0 + ky - P + (hp / HW_);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (y >= 0 && y < p.H && x >= 0 && x < p.W) v = *reinterpret_cast<const float4*>(g + ((size_t)y * p.W + x) * CIN + c4 * 4);
-                *reinterpret_cast<float4*>(Xs + hp * CIN + c4 * 4) = v;
-            }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int c4 = idx % FX, hp = idx / FX;
+            const int x = x0 - P + (hp % HW_), y = y0 + ky - P + (hp / HW_);
+            rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < XT && y >= 0 && y < p.H && x >= 0 && x < p.W) rx[i] = *reinterpret_cast<const float4*>(gx + ((size_t)y * p.W + x) * CIN + c4 * 4);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            *reinterpret_cast<float4*>(dYs + (idx / FY) * COUT + (idx % FY) * 4) = rdy[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            if (idx < XT) *reinterpret_cast<float4*>(Xs + (idx / FX) * CIN + (idx % FX) * 4) = rx[i];
         }
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);
         constexpr int R0N = TH / KSPLIT;
 #pragma unroll 1
         for (int rr = 0; rr < R0N; ++rr) {
