@@ -115,3 +115,39 @@ def test_schedules():
     assert tau == pytest.approx(0.1)
     tau, _ = O.schedules(cfg, 15000)
     assert tau == pytest.approx(0.55)
+
+
+# ------------------------------------------------------------------------------------------- IODINE
+@pytest.mark.parametrize("tag,over", [
+    ("tiny", dict(obs_size=16, num_slots=3, num_iterations=3)),
+    ("s32", dict(obs_size=32, num_slots=7, num_iterations=5)),
+])
+def test_iodine_oracle_matches_reference(golden_dir, tag, over):
+    from oracle import iodine_oracle as IO
+    fx = np.load(os.path.join(golden_dir, f"iodine_{tag}.npz"))
+    cfg = IO.default_cfg(**over)
+    B, seed = int(fx["B"]), int(fx["seed"])
+    g = torch.Generator().manual_seed(seed + 1000)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=g)
+    tr = IO.OracleTrainer(cfg, IO.formula_params(cfg))
+    step = 0
+    while f"s{step}.loss" in fx:
+        res = tr.update(obs, IO.make_noise(cfg, B, seed + step))
+        for k, r in (("loss", "loss"), ("mse", "mse"), ("kl", "kld"), ("norm", "norm")):
+            assert float(res[k]) == pytest.approx(float(fx[f"s{step}.{r}"]), rel=3e-5), (step, k)
+        step += 1
+    for n, ref in zip([str(n) for n in fx["param_names"]], fx["param_sums"]):
+        np.testing.assert_allclose(_summ(tr.P[n])[1:], ref[1:], rtol=5e-5, err_msg=n)
+    tr2 = IO.OracleTrainer(cfg, {n: p.detach() for n, p in tr.P.items()})
+    res, grads = tr2.loss_and_grads(obs, IO.make_noise(cfg, B, seed + step))
+    assert float(res["loss"]) == pytest.approx(float(fx["f.loss"]), rel=3e-5)
+    assert float(res["mse"]) == pytest.approx(float(fx["f.mse"]), rel=3e-5)
+    assert float(res["kl"]) == pytest.approx(float(fx["f.kl"]), rel=3e-5)
+    np.testing.assert_allclose(res["slots"].numpy(), fx["f.slots"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res["recon"].flatten()[:64].numpy(), fx["f.recon_head"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res["masks"].flatten()[:64].numpy(), fx["f.masks_head"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(_summ(res["masks"])[1:], fx["f.masks_sum"][1:], rtol=3e-5)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for n, ref in zip([str(n) for n in fx["grad_names"]], fx["grad_sums"]):
+        np.testing.assert_allclose(_summ(grads[n])[1:], ref[1:], rtol=1e-4, atol=1e-6 * gmax, err_msg=n)
+        np.testing.assert_allclose(grads[n].flatten()[:16].numpy(), fx["gradhead." + n], rtol=2e-4, atol=1e-6 * gmax, err_msg=n)
