@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define OCRL_ABI_VERSION 2
+#define OCRL_ABI_VERSION 3
 
 const char* ocrl_last_error(void);
 int ocrl_abi_version(void);
@@ -122,6 +122,38 @@ int ocrl_attention_bwd(const float* q, const float* k, const float* v, const flo
  * ocrl_prof_collect synchronises the device and returns total milliseconds / launch counts per tag. */
 int ocrl_prof_enable(unsigned tag_mask);
 int ocrl_prof_collect(double* ms, long long* count, int ntags);
+
+/* ---- IODINE (ocrs/iodine/iodine_module.py:14-271, ocrs/iodine/iodine.py:4-14, ocrs/base.py:60-74): SURVEY.md §8 row a20 ----
+ * Same conventions as the SLATE handle: flat fp32 parameter / gradient / Adam buffers in the reference's
+ * _module.parameters() order and state_dict names, adopted from the caller; one workspace; all work on the caller's stream. */
+typedef struct ocrl_iodine ocrl_iodine;
+typedef struct ocrl_iodine_config {
+    int obs_size, obs_channels;                 /* env_config.obs_size / obs_channels (3) */
+    int slot_size, num_iterations, num_slots;   /* ocr_config.slot_size / num_iterations / num_slots */
+    float sigma, beta;                          /* ocr_config.sigma / beta */
+    int layer_norm;                             /* ocr_config.layer_norm */
+    int ref_mlp_hidden;                         /* ocr_config.ref_mlp_hidden_size; conv widths 64, 4 layers, 3x3 (stride 2 / 1) are fixed */
+    int max_batch;
+} ocrl_iodine_config;
+int ocrl_iodine_create(const ocrl_iodine_config* cfg, ocrl_iodine** out);
+void ocrl_iodine_destroy(ocrl_iodine* h);
+int ocrl_iodine_param_count(const ocrl_iodine* h);
+int ocrl_iodine_param_info(const ocrl_iodine* h, int i, char* name, int name_cap, int shape[4], int* ndim, long long* offset, long long* numel);
+long long ocrl_iodine_flat_size(const ocrl_iodine* h);
+size_t ocrl_iodine_workspace_bytes(const ocrl_iodine* h);
+int ocrl_iodine_bind(ocrl_iodine* h, float* params, float* grads, float* adam_m, float* adam_v, void* workspace, size_t workspace_bytes);
+/* Iodine_Module._forward (iodine_module.py:79-252): obs [B,3,S,S] NCHW; noise: optional injected N(0,1) draws of the
+ * per-iteration rsample, [I,B,K,L] (NULL = device RNG stream `seed`).  Results: ocrl_iodine_metrics / ocrl_iodine_tensor
+ * ("slots" [B,K,L], "masks" [B,K,S,S], "recon" [B,3,S,S], "recons_masked" [B,K,3,S,S], "out4" [B*K,S,S,4]). */
+int ocrl_iodine_forward(ocrl_iodine* h, const float* obs, int B, unsigned long long seed, const float* noise, void* stream);
+/* loss.backward() of the last forward (loss = -sum_i (i+1)/I ELBO_i) into the flat gradient buffer */
+int ocrl_iodine_backward(ocrl_iodine* h, void* stream);
+/* clip_grad_norm_(params, clip, 2.0) + Adam(lr) (base.py:60-74); gscale = 1/world for a data-parallel mean */
+int ocrl_iodine_clip_adam(ocrl_iodine* h, float lr, float clip, int step, float gscale, void* stream);
+int ocrl_iodine_grad_norm(ocrl_iodine* h, void* stream);
+/* device float[8]: [0] loss, [1] mse (last iteration), [2] kld (last iteration), [3] gradient L2 norm */
+float* ocrl_iodine_metrics(const ocrl_iodine* h);
+int ocrl_iodine_tensor(const ocrl_iodine* h, const char* name, float** ptr, long long* count);
 
 #ifdef __cplusplus
 }

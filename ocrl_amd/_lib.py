@@ -14,6 +14,11 @@ class SlateConfig(ctypes.Structure):
                [("dropout", c_float), ("max_batch", c_int), ("use_bcdec", c_int)]
 
 
+class IodineConfig(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("obs_size", "obs_channels", "slot_size", "num_iterations", "num_slots")] + \
+               [("sigma", c_float), ("beta", c_float), ("layer_norm", c_int), ("ref_mlp_hidden", c_int), ("max_batch", c_int)]
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -62,7 +67,24 @@ def lib():
     L.ocrl_attention_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_uint, p]
     L.ocrl_prof_enable.argtypes = [c_uint]
     L.ocrl_prof_collect.argtypes = [POINTER(ctypes.c_double * 8), POINTER(c_longlong * 8), c_int]
-    if L.ocrl_abi_version() != 2:
+    L.ocrl_iodine_create.argtypes = [POINTER(IodineConfig), POINTER(p)]
+    L.ocrl_iodine_destroy.argtypes = [p]
+    L.ocrl_iodine_destroy.restype = None
+    L.ocrl_iodine_param_count.argtypes = [p]
+    L.ocrl_iodine_param_info.argtypes = [p, c_int, c_char_p, c_int, POINTER(c_int * 4), POINTER(c_int), POINTER(c_longlong), POINTER(c_longlong)]
+    L.ocrl_iodine_flat_size.argtypes = [p]
+    L.ocrl_iodine_flat_size.restype = c_longlong
+    L.ocrl_iodine_workspace_bytes.argtypes = [p]
+    L.ocrl_iodine_workspace_bytes.restype = c_size_t
+    L.ocrl_iodine_bind.argtypes = [p, p, p, p, p, p, c_size_t]
+    L.ocrl_iodine_forward.argtypes = [p, p, c_int, c_ulonglong, p, p]
+    L.ocrl_iodine_backward.argtypes = [p, p]
+    L.ocrl_iodine_clip_adam.argtypes = [p, c_float, c_float, c_int, c_float, p]
+    L.ocrl_iodine_grad_norm.argtypes = [p, p]
+    L.ocrl_iodine_metrics.argtypes = [p]
+    L.ocrl_iodine_metrics.restype = p
+    L.ocrl_iodine_tensor.argtypes = [p, c_char_p, POINTER(p), POINTER(c_longlong)]
+    if L.ocrl_abi_version() != 3:
         raise RuntimeError("libocrl_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -178,7 +178,7 @@ __global__ void bc_c4_pack_kernel(const float* __restrict__ W, float* __restrict
 
 template <int MODE>   // 0: forward (X [.,64] -> Y [.,4]);  1: backward data (dY [.,4] -> dX [.,64], masked by act > 0)
 __global__ __launch_bounds__(128) void bc_c4_conv_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias,
-                                                         const float* __restrict__ act, float* __restrict__ Y, int Bn, int S) {
+                                                         const float* __restrict__ act, float* __restrict__ Y, int Bn, int S, int elu) {
     constexpr int CI = MODE == 0 ? 64 : 4;
     constexpr int LD = MODE == 0 ? 68 : 4;
     constexpr int HW_ = BT_W + 2, HH_ = BT_H + 2;
@@ -244,7 +244,10 @@ __global__ __launch_bounds__(128) void bc_c4_conv_kernel(const float* __restrict
             const size_t o = ((b * S + yy) * S + xx) * 64 + c4 * 4;
             const float4 m = *reinterpret_cast<const float4*>(act + o);
             const float* sp = stage + p * 65 + c4 * 4;
-            *reinterpret_cast<float4*>(Y + o) = make_float4(m.x > 0.f ? sp[0] : 0.f, m.y > 0.f ? sp[1] : 0.f, m.z > 0.f ? sp[2] : 0.f, m.w > 0.f ? sp[3] : 0.f);
+            // gate by the derivative of the saved activation: ReLU' (m > 0) or ELU' (m > 0 ? 1 : m + 1)
+            const float e = elu ? 1.f : 0.f;
+            *reinterpret_cast<float4*>(Y + o) = make_float4(m.x > 0.f ? sp[0] : e * (m.x + 1.f) * sp[0], m.y > 0.f ? sp[1] : e * (m.y + 1.f) * sp[1],
+                                                            m.z > 0.f ? sp[2] : e * (m.z + 1.f) * sp[2], m.w > 0.f ? sp[3] : e * (m.w + 1.f) * sp[3]);
         }
     }
 }
@@ -395,14 +398,14 @@ int bc_c4_fwd_launch(const float* X, const float* Wk, const float* bias4, float*
     const int smem = (BT_H + 2) * (BT_W + 2) * 68 * 4;
     static bool set = false;
     if (!set) { OCRL_HIP(hipFuncSetAttribute((const void*)bc_c4_conv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); set = true; }
-    hipLaunchKernelGGL((bc_c4_conv_kernel<0>), dim3(grid), dim3(128), smem, st, X, Wk, bias4, nullptr, Y, Bn, S);
+    hipLaunchKernelGGL((bc_c4_conv_kernel<0>), dim3(grid), dim3(128), smem, st, X, Wk, bias4, nullptr, Y, Bn, S, 0);
     OCRL_CHECK_LAUNCH("bc_c4_fwd");
     return 0;
 }
-int bc_c4_bwd_data_launch(const float* dY, const float* Wb, const float* act, float* dX, int Bn, int S, hipStream_t st) {
+int bc_c4_bwd_data_launch(const float* dY, const float* Wb, const float* act, float* dX, int Bn, int S, hipStream_t st, int elu) {
     const int grid = cdiv(S, BT_W) * cdiv(S, BT_H) * Bn;
     const int smem = ((BT_H + 2) * (BT_W + 2) * 4 + 128 * 65) * 4;
-    hipLaunchKernelGGL((bc_c4_conv_kernel<1>), dim3(grid), dim3(128), smem, st, dY, Wb, nullptr, act, dX, Bn, S);
+    hipLaunchKernelGGL((bc_c4_conv_kernel<1>), dim3(grid), dim3(128), smem, st, dY, Wb, nullptr, act, dX, Bn, S, elu);
     OCRL_CHECK_LAUNCH("bc_c4_bwd_data");
     return 0;
 }

@@ -5,6 +5,7 @@
 #include <new>
 
 #include "../../include/ocrl_hip.h"
+#include "iodine_model.h"
 #include "slate_model.h"
 
 static thread_local char g_err[512] = "";
@@ -18,6 +19,10 @@ void ocrl_set_error(const char* fmt, ...) {
 
 struct ocrl_slate {
     SlateModel* m;
+};
+
+struct ocrl_iodine {
+    IodineModel* m;
 };
 
 #define ST(s) static_cast<hipStream_t>(s)
@@ -162,4 +167,57 @@ int ocrl_attention_bwd(const float* q, const float* k, const float* v, const flo
     return attn_launch(a, 1, ST(stream));
 }
 
+
+// ---------------------------------------------------------------- IODINE
+int ocrl_iodine_create(const ocrl_iodine_config* c, ocrl_iodine** out) {
+    if (!c || !out) { ocrl_set_error("ocrl_iodine_create: null argument"); return 1; }
+    if (c->obs_size < 16 || c->obs_size % 16 || c->obs_channels != 3 || c->slot_size < 4 || c->slot_size % 4 || c->slot_size > 256 ||
+        c->num_iterations < 1 || c->num_slots < 1 || c->num_slots > 16 || c->ref_mlp_hidden < 64 || c->ref_mlp_hidden % 64 || c->max_batch < 1 ||
+        !(c->sigma > 0.f)) {
+        ocrl_set_error("ocrl_iodine_create: invalid configuration");
+        return 1;
+    }
+    IodineConfig k;
+    k.obs_size = c->obs_size; k.obs_channels = c->obs_channels; k.slot_size = c->slot_size; k.num_iters = c->num_iterations;
+    k.num_slots = c->num_slots; k.sigma = c->sigma; k.beta = c->beta; k.layer_norm = c->layer_norm; k.ref_mlp_hidden = c->ref_mlp_hidden;
+    k.max_batch = c->max_batch;
+    ocrl_iodine* h = new (std::nothrow) ocrl_iodine;
+    if (!h) { ocrl_set_error("out of memory"); return 1; }
+    h->m = new (std::nothrow) IodineModel(k);
+    if (!h->m) { delete h; ocrl_set_error("out of memory"); return 1; }
+    *out = h;
+    return 0;
+}
+void ocrl_iodine_destroy(ocrl_iodine* h) {
+    if (!h) return;
+    delete h->m;
+    delete h;
+}
+int ocrl_iodine_param_count(const ocrl_iodine* h) { return (h && h->m) ? (int)h->m->params().size() : -1; }
+int ocrl_iodine_param_info(const ocrl_iodine* h, int i, char* name, int name_cap, int shape[4], int* ndim, long long* offset, long long* numel) {
+    GUARD(h);
+    if (i < 0 || i >= (int)h->m->params().size()) { ocrl_set_error("param index out of range"); return 1; }
+    const ParamInfo& p = h->m->params()[i];
+    if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+    if (ndim) *ndim = p.ndim;
+    if (offset) *offset = p.offset;
+    if (numel) *numel = p.numel;
+    return 0;
+}
+long long ocrl_iodine_flat_size(const ocrl_iodine* h) { return (h && h->m) ? h->m->flat_size() : -1; }
+size_t ocrl_iodine_workspace_bytes(const ocrl_iodine* h) { return (h && h->m) ? h->m->workspace_bytes() : 0; }
+int ocrl_iodine_bind(ocrl_iodine* h, float* p, float* g, float* m, float* v, void* ws, size_t n) { GUARD(h); return h->m->bind(p, g, m, v, ws, n); }
+int ocrl_iodine_forward(ocrl_iodine* h, const float* obs, int B, unsigned long long seed, const float* noise, void* stream) {
+    GUARD(h);
+    return h->m->forward(obs, B, seed, noise, ST(stream));
+}
+int ocrl_iodine_backward(ocrl_iodine* h, void* stream) { GUARD(h); return h->m->backward(ST(stream)); }
+int ocrl_iodine_clip_adam(ocrl_iodine* h, float lr, float clip, int step, float gscale, void* stream) {
+    GUARD(h);
+    return h->m->clip_adam(lr, clip, step, gscale, ST(stream));
+}
+int ocrl_iodine_grad_norm(ocrl_iodine* h, void* stream) { GUARD(h); return h->m->grad_norm(ST(stream)); }
+float* ocrl_iodine_metrics(const ocrl_iodine* h) { return (h && h->m) ? h->m->metrics() : nullptr; }
+int ocrl_iodine_tensor(const ocrl_iodine* h, const char* name, float** ptr, long long* count) { GUARD(h); return h->m->tensor(name, ptr, count); }
 }  // extern "C"

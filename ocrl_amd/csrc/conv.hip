@@ -149,10 +149,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
             const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (x >= p.W) continue;
             float v = (tn == 0 ? acc0[r] : acc1[r]) + bv;
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.relu == 1) v = fmaxf(v, 0.f);
+            else if (p.relu == 2) v = v > 0.f ? v : __expf(v) - 1.f;
             const size_t pix = ((size_t)b * p.H + y) * p.W + x;
             if (p.posmap) v += p.posmap[((size_t)y * p.W + x) * COUT + co];
-            if (p.mask) v = p.mask[pix * COUT + co] > 0.f ? v : 0.f;
+            if (p.mask) {
+                const float mk = p.mask[pix * COUT + co];
+                v = mk > 0.f ? v : (p.mask_elu ? v * (mk + 1.f) : 0.f);
+            }
             p.Y[pix * COUT + co] = v;
         }
     }

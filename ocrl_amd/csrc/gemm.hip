@@ -266,13 +266,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 float v = acc[i][j][r] * p.alpha;
                 if (!partial) {
                     v += bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu == 1) v = fmaxf(v, 0.f);
+                    else if (p.relu == 2) v = v > 0.f ? v : __expf(v) - 1.f;      // ELU
                     if (p.drop_p > 0.f) {
                         const uint64_t idx = ((uint64_t)batch * p.M + row) * (uint64_t)p.N + col;
                         const uint2 bits = rng_bits4(p.drop_seed, p.drop_site, idx >> 2);
                         v = rng_keep(bits, (int)(idx & 3), thr) ? v * dscale : 0.f;
                     }
-                    if (Mk) v = Mk[(size_t)row * p.ldmask + col] > 0.f ? v : 0.f;
+                    if (Mk) {
+                        const float mk = Mk[(size_t)row * p.ldmask + col];
+                        v = mk > 0.f ? v : (p.mask_elu ? v * (mk + 1.f) : 0.f);     // ReLU' / ELU' of the saved activation
+                    }
                     if (R) v += R[(size_t)row * p.ldr + col];
                 }
                 C[(size_t)row * p.ldc + col] = v;

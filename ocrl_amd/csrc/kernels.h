@@ -25,11 +25,12 @@ struct GemmArgs {
     // epilogue (ignored when splitk > 1):  v = alpha*acc + bias[n]; relu; dropout; *(mask>0); + resid
     float alpha = 1.f;
     const float* bias = nullptr;
-    int relu = 0;
+    int relu = 0;                         // 0 none, 1 ReLU, 2 ELU
     float drop_p = 0.f;
     unsigned long long drop_seed = 0;
     unsigned drop_site = 0;
     const float* mask = nullptr; int ldmask = 0; long long sMask = 0;
+    int mask_elu = 0;                     // mask holds ELU outputs: v *= (m > 0 ? 1 : m + 1) instead of the ReLU gate
     const float* resid = nullptr; int ldr = 0; long long sR = 0;
     // A-operand dropout (backward of y = x + dropout(branch)): A element (m, n) of the logical row-major [rows, adrop_ld]
     // tensor is multiplied by keep/(1-p) of dropout site adrop_site while it is staged (no separate mask pass)
@@ -48,9 +49,10 @@ struct ConvArgs {
     float* Y = nullptr;             // [B,H,W,COUT]
     int B = 0, H = 0, W = 0;
     const float* bias = nullptr;    // [COUT]
-    int relu = 0;
+    int relu = 0;                   // 0 none, 1 ReLU, 2 ELU
     const float* posmap = nullptr;  // [H,W,COUT] added after bias/relu
     const float* mask = nullptr;    // [B,H,W,COUT]: output zeroed where mask <= 0 (ReLU backward)
+    int mask_elu = 0;               // mask holds ELU outputs: v *= (m > 0 ? 1 : m + 1)
     int diag = 0;                   // development diagnostic (OCRL_CONV_DIAG): wrong results, timing only
 };
 struct WgradArgs {
@@ -187,8 +189,38 @@ int bc_compose_bwd_launch(const float* W1, const float* Wpos, const float* bpos,
                           float* dWpos, float* dbpos, int D, hipStream_t st);
 int bc_c4_pack_launch(const float* W, float* Wk, float* Wb, int co_n, hipStream_t st);
 int bc_c4_fwd_launch(const float* X, const float* Wk, const float* bias4, float* Y, int Bn, int S, hipStream_t st);
-int bc_c4_bwd_data_launch(const float* dY, const float* Wb, const float* act, float* dX, int Bn, int S, hipStream_t st);
+int bc_c4_bwd_data_launch(const float* dY, const float* Wb, const float* act, float* dX, int Bn, int S, hipStream_t st, int elu = 0);
 int bc_c4_wgrad_blocks(int Bn, int S);
 int bc_c4_wgrad_launch(const float* X, const float* dY, float* part, int Bn, int S, hipStream_t st);
 int bc_mix_launch(const float* out4, const float* obs, float* recon, float* dout4, float* loss_out, int B, int K, int S, int C, float* ws,
                   size_t ws_floats, hipStream_t st);
+
+// ------------------------------------------------------------------ iodine.hip (IODINE: ocrs/iodine/iodine_module.py)
+int io_sample_launch(const float* mu, const float* ls, const float* noise, float* eps_out, float* slots, float* kl_out, long long n,
+                     unsigned long long seed, unsigned site, hipStream_t st);
+int io_w1_pack_launch(const float* W1, float* W1r, float* Wxy, int L, hipStream_t st);
+int io_p1_launch(const float* Wxy, const float* b1, float* P1, int S, hipStream_t st);
+int io_class_sum_launch(const float* in, float* out, long long BK, int forward, hipStream_t st);
+int io_layer1_launch(const float* P1, const float* T, float* c1, long long BK, int S, hipStream_t st);
+int io_layer1_bwd_launch(const float* g, float* dT, long long BK, int S, hipStream_t st);
+int io_w1_grad_launch(const float* dW1r, const float* G, float* dW1, float* db1, int S, int L, hipStream_t st);
+int io_elbo_launch(const float* out4, const float* obs, int B, int K, int S, float sigma, float* enc, float* st1, float* dout4, float* part,
+                   float* masks_out, float* recon_out, float* rmasked_out, hipStream_t st);
+int io_enc_norm_launch(float* enc, const float* st1, float* st2, long long BK, int N, hipStream_t st);
+int io_elbo_bwd_launch(const float* out4, const float* obs, const float* denc, int B, int K, int S, float sigma, float cw, float* dout4, hipStream_t st);
+int io_latent_launch(const float* mu, const float* ls, const float* eps, const float* ds, float* latent, long long BK, int L, float beta, int layer_norm,
+                     int ld, hipStream_t st);
+int io_im2col_launch(const float* x, float* col, long long Bn, int C, int Hi, int Wi, int ldc, hipStream_t st);
+int io_col2im_launch(const float* dcol, const float* act, float* dx, long long Bn, int C, int Hi, int Wi, int ldc, hipStream_t st);
+int io_refw_pack_launch(const float* W, float* Wp, int C, int ldc, hipStream_t st);
+int io_refw_unpack_launch(const float* dWp, float* dW, int C, int ldc, hipStream_t st);
+int io_pool_launch(const float* r, float* pool, long long BK, int n, hipStream_t st);
+int io_pool_bwd_launch(const float* dpool, const float* r, float* dpre, long long BK, int n, hipStream_t st);
+int io_elu2_launch(const float* a, int lda, float* y, int ldy, long long rows, int F, const float* dy, int lddy, hipStream_t st);
+int io_lstm_fwd_launch(const float* gates, const float* c0, float* acts, float* c1, float* h1, long long rows, int H, hipStream_t st);
+int io_lstm_bwd_launch(const float* acts, const float* c0, const float* c1, const float* dh1, const float* dc1, float* dgates, float* dc0,
+                       long long rows, int H, hipStream_t st);
+int io_post_grad_launch(const float* mu, const float* ls, const float* eps, const float* ds, const float* dlat, int ldl, float kw, float* gmu,
+                        float* gls, long long BK, int L, hipStream_t st);
+int io_l2norm_launch(const float* g, long long n, float* out, hipStream_t st);
+int io_loss_launch(const float* parts, float* metrics, int I, int B, float beta, hipStream_t st);

@@ -140,3 +140,86 @@ class SlateEngine:
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         _lib.check(self.L.ocrl_slate_dropout_mask(self.h, int(site), n, _lib.ptr(out), self.stream))
         return out.view(shape)
+
+
+class IodineEngine:
+    """Same role as SlateEngine for the IODINE handle (include/ocrl_hip.h: ocrl_iodine_*)."""
+
+    def __init__(self, dims, max_batch, device="cuda:0", with_optimizer=True):
+        """dims: namespace with obs_size, obs_channels, slot_size, num_iterations, num_slots, sigma, beta, layer_norm, ref_mlp_hidden."""
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"ocrl_amd runs on an AMD GPU only (device={device!r}); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ocrl_amd: no GPU visible to PyTorch-ROCm")
+        self.L = _lib.lib()
+        self.device = dev
+        self.dims = dims
+        self.max_batch = int(max_batch)
+        c = _lib.IodineConfig(dims.obs_size, dims.obs_channels, dims.slot_size, dims.num_iterations, dims.num_slots, float(dims.sigma),
+                              float(dims.beta), int(bool(dims.layer_norm)), dims.ref_mlp_hidden, self.max_batch)
+        h = ctypes.c_void_p()
+        _lib.check(self.L.ocrl_iodine_create(ctypes.byref(c), ctypes.byref(h)))
+        self.h = h
+        self.params = []
+        name = ctypes.create_string_buffer(256)
+        shape = (ctypes.c_int * 4)()
+        nd, off, ne = ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong()
+        for i in range(self.L.ocrl_iodine_param_count(h)):
+            _lib.check(self.L.ocrl_iodine_param_info(h, i, name, 256, ctypes.byref(shape), ctypes.byref(nd), ctypes.byref(off), ctypes.byref(ne)))
+            self.params.append(SimpleNamespace(name=name.value.decode(), shape=tuple(shape[k] for k in range(nd.value)), offset=off.value,
+                                               numel=ne.value, group=0))
+        self.flat_size = self.L.ocrl_iodine_flat_size(h)
+        with torch.cuda.device(dev):
+            mk = lambda: _aligned_empty(self.flat_size * 4, dev).view(torch.float32).zero_()
+            self.flat_p, self.flat_g = mk(), mk()
+            self.flat_m, self.flat_v = (mk(), mk()) if with_optimizer else (None, None)
+            self.ws_bytes = self.L.ocrl_iodine_workspace_bytes(h)
+            self.ws = _aligned_empty(self.ws_bytes, dev)
+            _lib.check(self.L.ocrl_iodine_bind(h, _lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v),
+                                               _lib.ptr(self.ws), self.ws_bytes))
+        self.metrics = self._view(self.L.ocrl_iodine_metrics(h), 8, torch.float32)
+        self.adam_step = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.ocrl_iodine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    _view = SlateEngine._view
+    view = SlateEngine.view
+    param = SlateEngine.param
+    grad = SlateEngine.grad
+    stream = SlateEngine.stream
+
+    def tensor(self, name, shape, dtype=torch.float32):
+        p, n = ctypes.c_void_p(), ctypes.c_longlong()
+        _lib.check(self.L.ocrl_iodine_tensor(self.h, name.encode(), ctypes.byref(p), ctypes.byref(n)))
+        cnt = 1
+        for s in shape:
+            cnt *= s
+        assert cnt <= n.value, (name, shape, n.value)
+        return self._view(p.value, cnt, dtype).view(shape)
+
+    def forward(self, obs, seed, noise=None):
+        """obs [B,3,S,S] fp32 contiguous on device; noise: optional [I,B,K,L] N(0,1) draws."""
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous()
+        assert noise is None or (noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous())
+        self._keep = (obs, noise)
+        _lib.check(self.L.ocrl_iodine_forward(self.h, _lib.ptr(obs), obs.shape[0], int(seed), _lib.ptr(noise), self.stream))
+        return self.metrics
+
+    def backward(self):
+        _lib.check(self.L.ocrl_iodine_backward(self.h, self.stream))
+
+    def clip_adam(self, lr, clip, grad_scale=1.0):
+        self.adam_step += 1
+        _lib.check(self.L.ocrl_iodine_clip_adam(self.h, float(lr), float(clip if clip is not None else 0.0), self.adam_step, float(grad_scale),
+                                                self.stream))
+
+    def grad_norm(self):
+        _lib.check(self.L.ocrl_iodine_grad_norm(self.h, self.stream))
+        return self.metrics[3]

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.ocrl_abi_version() == 2
+    assert L.ocrl_abi_version() == 3
 
 
 @pytest.mark.parametrize("over", [dict(obs_size=64), dict(obs_size=128, num_slots=6), dict(obs_size=16, vocab_size=256, num_dec_blocks=2),
@@ -71,3 +71,31 @@ def test_engine_refuses_cpu_device():
     from tests.gpu_util import dims_from_cfg
     with pytest.raises(RuntimeError):
         SlateEngine(dims_from_cfg(O.default_cfg()), 1, device="cpu")
+
+
+@pytest.mark.parametrize("over", [dict(), dict(obs_size=16, num_slots=3, num_iterations=3, slot_size=32)])
+def test_iodine_param_table_matches_reference_inventory(over):
+    from ocrl_amd import _lib
+    from oracle import iodine_oracle as IO
+    L = _lib.lib()
+    cfg = IO.default_cfg(**over)
+    c = _lib.IodineConfig(cfg.obs_size, 3, cfg.slot_size, cfg.num_iterations, cfg.num_slots, cfg.sigma, cfg.beta, 1, cfg.ref_mlp_hidden, 2)
+    h = ctypes.c_void_p()
+    _lib.check(L.ocrl_iodine_create(ctypes.byref(c), ctypes.byref(h)))
+    try:
+        spec = IO.param_shapes(cfg)
+        assert L.ocrl_iodine_param_count(h) == len(spec)
+        name = ctypes.create_string_buffer(256)
+        shape = (ctypes.c_int * 4)()
+        nd, off, ne = ctypes.c_int(), ctypes.c_longlong(), ctypes.c_longlong()
+        prev_end = 0
+        for i, (n, s, _) in enumerate(spec):
+            _lib.check(L.ocrl_iodine_param_info(h, i, name, 256, ctypes.byref(shape), ctypes.byref(nd), ctypes.byref(off), ctypes.byref(ne)))
+            assert name.value.decode() == n and tuple(shape[k] for k in range(nd.value)) == tuple(s) and ne.value == int(np.prod(s))
+            assert off.value % 4 == 0 and off.value >= prev_end
+            prev_end = off.value + ne.value
+        assert L.ocrl_iodine_flat_size(h) >= prev_end and L.ocrl_iodine_workspace_bytes(h) > 0
+    finally:
+        L.ocrl_iodine_destroy(h)
+    bad = _lib.IodineConfig(40, 3, 64, 5, 7, 0.35, 1.0, 1, 256, 1)           # obs_size not a multiple of 16
+    assert L.ocrl_iodine_create(ctypes.byref(bad), ctypes.byref(h)) != 0 and b"invalid" in L.ocrl_last_error()
