@@ -65,6 +65,67 @@ def cpu_baseline(obs_size, batch, steps):
                       f"1 warm-up + {steps} timed steps, {t:.2f} s/step"}
 
 
+def bench_iodine(args, dev, dist, rank, world):
+    """BASELINE config 4: IODINE update() = _forward + backward + all-reduce + L2 clip + Adam (the per-step CPU ARI metric of
+    get_loss is excluded from the timed region, like SLATE's masks=None path)."""
+    from ocrl_amd import ocrs
+    from ocrl_amd.dist_utils import allreduce_grads_
+    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+    S, B, K = args.obs_size, args.batch, args.num_slots
+    ocr = NS(name="Iodine", slot_size=64, num_iterations=5, num_slots=K, img_channels=3, sigma=0.35, beta=1.0, layer_norm=True,
+             ref_cnn_hidden_size=64, ref_mlp_hidden_size=256, ref_cnn_layers=4, ref_cnn_kernel_size=3, ref_cnn_stride_size=2,
+             dec_cnn_hidden_size=64, dec_cnn_layers=4, dec_cnn_kernel_size=3, learning=NS(lr=3e-4, clip=5.0, clip_norm_type=2.0))
+    torch.manual_seed(0)
+    model = ocrs.Iodine(ocr, NS(obs_size=S, obs_channels=3))
+    model._module._max_batch = B
+    model.to(dev)
+    model.train()
+    model._module.set_seed(1 + rank)
+    pool = [scenes_to_obs(random_sprite_scenes(B, S, seed=1000 * rank + i)).to(dev) for i in range(4)]
+    mod, lr = model._module, ocr.learning
+
+    def step_fn(i):
+        out = mod._forward(pool[i % len(pool)])
+        mod.backward()
+        scale = allreduce_grads_(mod.engine.flat_g)
+        model._opt.step(lr.clip, scale)
+        return out[4]
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+
+    n = 0
+    for _ in range(args.warmup):
+        step_fn(n); n += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step_fn(n); n += 1
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ips = B * world * args.steps / dt
+        # decoder 1.236 GF per (image, slot, iteration) forward at 64x64 (SURVEY.md §8a row a20): fwd I, in-forward bwd-data I-1, bwd 2I
+        dec = 2.0 * 9 * (66 * 64 + 3 * 64 * 64 + 64 * 4) * S * S
+        flop_img = dec * K * (5 + 4 + 2 * 5)
+        print(json.dumps({
+            "metric": f"images/sec (node) IODINE pretrain {S}x{S}, {K} slots, 5 iters", "value": round(ips, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"IODINE {S}x{S}, {K} slots, 5 refinement iterations; _forward + backward + all-reduce + L2 clip + Adam "
+                                   f"(CPU ARI metric excluded), device RNG; random-N5C4S4S2-style scenes",
+                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
+            "decoder_mfma_frac": round(ips / world * flop_img / (PEAK_MFMA_F32_TFLOPS * 1e12), 4), "final_loss": round(float(loss.item()), 4)}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,7 +135,8 @@ def main():
     ap.add_argument("--obs-size", type=int, default=128)
     ap.add_argument("--num-slots", type=int, default=6, help="6 = headline; 16 with --obs-size 256 = BASELINE config 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["slate", "slotattn"], default="slate", help="slotattn = BASELINE config 2 (use_bcdec); headline = slate")
+    ap.add_argument("--workload", choices=["slate", "slotattn", "iodine"], default="slate",
+                    help="slotattn = BASELINE config 2 (use_bcdec); iodine = config 4 (use --obs-size 64 --num-slots 7); headline = slate")
     ap.add_argument("--dropout", type=float, default=0.1, help="diagnostic only: the headline number uses the reference default 0.1")
     args = ap.parse_args()
 
@@ -93,6 +155,8 @@ def main():
     from ocrl_amd import _lib, ocrs
     from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
     S, B = args.obs_size, args.batch
+    if args.workload == "iodine":
+        return bench_iodine(args, dev, dist, rank, world)
     ocr, env = slate_config(S, num_slots=args.num_slots)
     ocr.learning.dropout = args.dropout
     ocr.use_bcdec = args.workload == "slotattn"

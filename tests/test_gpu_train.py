@@ -55,3 +55,20 @@ def test_checkpoint_round_trip_restores_weights_and_adam_state():
     for (n1, p1), (n2, p2) in zip(a._module.named_parameters(), b._module.named_parameters()):
         if p1.dtype == torch.float32:
             assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-7), n1
+
+
+def test_train_ocr_runs_iodine(tmp_path):
+    """BASELINE config 4 plumbing: `train_ocr.py ocr=iodine` with masks from the synthetic dataset (ARI is reported)"""
+    import train_ocr
+    run = str(tmp_path / "run_iodine")
+    args = ["ocr=iodine", "ocr.num_slots=7", "ocr.num_iterations=5", "dataset=random-N5C4S4S2", "dataset.with_masks=True", "dataset.obs_size=32",
+            "device=cuda:0", "batch_size=4", "num_workers=0", "dataset.synthetic_train=32", "dataset.synthetic_val=8", "eval_interval=4",
+            "max_steps=8", "log_interval=1", f"run_dir={run}"]
+    assert train_ocr.main(args) == 8
+    lines = [json.loads(l) for l in open(os.path.join(run, "metrics.jsonl"))]
+    tr = [l for l in lines if "train/loss" in l]
+    assert len(tr) == 8 and all(torch.isfinite(torch.tensor(l["train/loss"])) for l in tr)
+    assert {"train/mse", "train/ari", "train/kld", "train/norm"} <= set(tr[0])
+    assert tr[-1]["train/loss"] < tr[0]["train/loss"]
+    ck = torch.load(os.path.join(run, "checkpoints", "model_latest.pth"), weights_only=True)
+    assert "refine.lstm.weight_ih" in ck["ocr_module_state_dict"] and ck["step"] == 8
