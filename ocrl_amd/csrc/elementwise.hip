@@ -59,20 +59,32 @@ __global__ void patchify4_kernel(const float* __restrict__ in, float* __restrict
 }
 
 // PixelShuffle(2) in NHWC: out[b, 2h+i, 2w+j, c] = in[b, h, w, 4c + 2i + j]; forward==0 runs the inverse map.
+// One thread per (b, h, w, c): the four sub-pixels of a channel are one float4 of the unshuffled tensor, and consecutive
+// threads (channels) touch consecutive floats of each shuffled pixel, so both sides move in full cache lines.
 __global__ void pixel_shuffle_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h, int w, int Cout, int forward,
                                      const float* __restrict__ mask) {
-    const long long n = (long long)B * h * w * 4 * Cout;
+    const long long n = (long long)B * h * w * Cout;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // enumerate the shuffled tensor [B,2h,2w,Cout]
     const int c = i % Cout;
     long long r = i / Cout;
-    const int X = r % (2 * w); r /= (2 * w);
-    const int Y = r % (2 * h);
-    const long long b = r / (2 * h);
-    const long long src = ((b * h + (Y >> 1)) * w + (X >> 1)) * (4 * Cout) + 4 * c + 2 * (Y & 1) + (X & 1);
-    if (forward) out[i] = in[src];
-    else out[src] = (mask && !(mask[src] > 0.f)) ? 0.f : in[i];     // backward: optional ReLU mask on the unshuffled tensor
+    const int x = r % w; r /= w;
+    const int y = r % h;
+    const long long b = r / h;
+    const long long u = i * 4;                                                      // unshuffled [b,h,w,4c..4c+3]
+    const long long s00 = ((b * 2 * h + 2 * y) * (2 * w) + 2 * x) * Cout + c;       // shuffled (2y, 2x)
+    const long long s01 = s00 + Cout, s10 = s00 + (long long)2 * w * Cout, s11 = s10 + Cout;
+    if (forward) {
+        const float4 v = *reinterpret_cast<const float4*>(in + u);
+        out[s00] = v.x; out[s01] = v.y; out[s10] = v.z; out[s11] = v.w;
+    } else {          // backward: optional ReLU mask on the unshuffled tensor
+        float4 v = make_float4(in[s00], in[s01], in[s10], in[s11]);
+        if (mask) {
+            const float4 m = *reinterpret_cast<const float4*>(mask + u);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(out + u) = v;
+    }
 }
 
 // ------------------------------------------------------------------ LayerNorm (eps 1e-5, biased variance)
@@ -158,6 +170,40 @@ __global__ void colsum_kernel(const float* __restrict__ X, long long ld, float* 
     red[rl][threadIdx.x & 63] = s;
     __syncthreads();
     if (rl == 0 && col < F) part[(size_t)blockIdx.y * F + col] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// float4 variant (F, ld multiples of 4; F <= 1024): a block owns whole rows of its chunk — thread = (row lane, float4 column),
+// four independent row streams per thread keep enough loads in flight to run at HBM speed.
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ X, long long ld, float* __restrict__ part, long long R, int F,
+                                                      long long rows_per_chunk) {
+    __shared__ float4 red[256];
+    const int F4 = F >> 2, RL = 256 / F4;            // row lanes per block
+    const int c4 = threadIdx.x % F4, rl = threadIdx.x / F4;
+    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
+    const long long r1 = min(R, r0 + rows_per_chunk);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    if (rl < RL) {
+        const float* base = X + (size_t)c4 * 4;
+        long long r = r0 + rl;
+        for (; r + 3 * RL < r1; r += 4 * RL) {
+            const float4 a = *reinterpret_cast<const float4*>(base + r * ld), b = *reinterpret_cast<const float4*>(base + (r + RL) * ld);
+            const float4 c = *reinterpret_cast<const float4*>(base + (r + 2 * RL) * ld), d = *reinterpret_cast<const float4*>(base + (r + 3 * RL) * ld);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+            s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+        }
+        for (; r < r1; r += RL) {
+            const float4 a = *reinterpret_cast<const float4*>(base + r * ld);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    red[threadIdx.x] = make_float4(s0.x + s1.x + s2.x + s3.x, s0.y + s1.y + s2.y + s3.y, s0.z + s1.z + s2.z + s3.z, s0.w + s1.w + s2.w + s3.w);
+    __syncthreads();
+    if (threadIdx.x < F4) {
+        float4 t = red[threadIdx.x];
+        for (int k = 1; k < RL; ++k) { const float4 v = red[k * F4 + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * F + threadIdx.x * 4) = t;
+    }
 }
 // out[c] (+)= scale * sum_k part[k][c]: 64 columns x 16 partial-row lanes per block (the partials are read in
 // parallel, not as one serial chain per column)
@@ -292,10 +338,20 @@ __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __rest
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ z, float* __restrict__ d, int V, float scale) {
     __shared__ float red[4];
     const long long row = blockIdx.x;
+    const int npt = V / 256;                 // V % 256 == 0, V <= 256 * GS_MAXPT: one read of z and d, one write
+    float zz[GS_MAXPT], dd[GS_MAXPT];
     float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) s += z[row * V + v] * d[row * V + v];
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) {
+            zz[i] = z[row * V + i * 256 + threadIdx.x];
+            dd[i] = d[row * V + i * 256 + threadIdx.x];
+            s += zz[i] * dd[i];
+        }
     s = block_sum(s, red);
-    for (int v = threadIdx.x; v < V; v += 256) d[row * V + v] = z[row * V + v] * (d[row * V + v] - s) * scale;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) d[row * V + i * 256 + threadIdx.x] = zz[i] * (dd[i] - s) * scale;
 }
 
 // cross entropy with hard targets, one workgroup per row: part[row] = lse - pred[tok];
@@ -306,20 +362,32 @@ __global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ pred, const
     const long long row = blockIdx.x;
     float* r = pred + row * V;
     const int tok = tokens[row];
-    const float rt = r[tok];                 // read before anyone overwrites the row with its gradient
-    float mx = -INFINITY;
-    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, r[v]);
+    const int npt = V / 256;                 // V % 256 == 0, V <= 256 * GS_MAXPT: the row lives in registers (one read, one exp, one write)
+    float x[GS_MAXPT];
+    float mx = -INFINITY, rt = 0.f;
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) {
+            x[i] = r[i * 256 + threadIdx.x];
+            mx = fmaxf(mx, x[i]);
+            if (i * 256 + (int)threadIdx.x == tok) rt = x[i];
+        }
     mx = block_max(mx, red);
     float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += 256) s += __expf(r[v] - mx);
+#pragma unroll
+    for (int i = 0; i < GS_MAXPT; ++i)
+        if (i < npt) { x[i] = __expf(x[i] - mx); s += x[i]; }
     s = block_sum(s, red);
+    rt = block_sum(rt, red);                 // exactly one thread holds the target logit
     if (threadIdx.x == 0) part[row] = (mx + __logf(s)) - rt;
     if (write_grad) {
         const float inv = 1.0f / s;
-        for (int v = threadIdx.x; v < V; v += 256) {
-            const float pr = __expf(r[v] - mx) * inv;
-            r[v] = (pr - (v == tok ? 1.f : 0.f)) * inv_b;
-        }
+#pragma unroll
+        for (int i = 0; i < GS_MAXPT; ++i)
+            if (i < npt) {
+                const int v = i * 256 + threadIdx.x;
+                r[v] = (x[i] * inv - (v == tok ? 1.f : 0.f)) * inv_b;
+            }
     }
 }
 
@@ -776,7 +844,7 @@ int patchify4_launch(const float* in, float* out, int B, int C, int S, hipStream
     return 0;
 }
 int pixel_shuffle_launch(const float* in, float* out, int B, int h, int w, int Cout, int forward, const float* mask, hipStream_t st) {
-    const long long n = (long long)B * h * w * 4 * Cout;
+    const long long n = (long long)B * h * w * Cout;
     hipLaunchKernelGGL(pixel_shuffle_kernel, GRID1D(n), 0, st, in, out, B, h, w, Cout, forward, mask);
     OCRL_CHECK_LAUNCH("pixel_shuffle");
     return 0;
@@ -794,6 +862,20 @@ int layernorm_fwd_launch(const float* x, const float* g, const float* b, float* 
     return 0;
 }
 int colsum_launch(const float* X, long long ld, float* out, long long R, int F, int accumulate, float scale, float* ws, size_t ws_floats, hipStream_t st) {
+    if (F % 4 == 0 && ld % 4 == 0 && F <= 1024 && F >= 4 && (((uintptr_t)X) & 15) == 0 && R >= 1024) {
+        long long nchunk = 2048;
+        if (nchunk > R / 64) nchunk = R / 64;
+        if ((size_t)nchunk * F > ws_floats) nchunk = (long long)(ws_floats / F);
+        if (nchunk >= 16) {
+            const long long rpc = (R + nchunk - 1) / nchunk;
+            nchunk = (R + rpc - 1) / rpc;
+            hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)nchunk), dim3(256), 0, st, X, ld, ws, R, F, rpc);
+            OCRL_CHECK_LAUNCH("colsum4");
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 64)), dim3(1024), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
+            OCRL_CHECK_LAUNCH("colsum_final");
+            return 0;
+        }
+    }
     const int cb = cdiv(F, 64);
     long long nchunk = 1024 / cb;
     if (nchunk < 1) nchunk = 1;
@@ -811,7 +893,8 @@ int layernorm_bwd_launch(const float* dy, const float* x, const float* mean, con
                          float* dgb, long long R, int F, int accumulate_dx, int accumulate_dgb, float* ws, size_t ws_floats, hipStream_t st) {
     OCRL_REQUIRE(F % 64 == 0 && F >= 64 && F <= 256, "layernorm bwd: F must be 64..256, multiple of 64 (got %d)", F);
     int nblk = (int)((R + 3) / 4);
-    if (nblk > 512) nblk = 512;
+    if (nblk > 2048) nblk = 2048;         // 8 waves per SIMD: the kernel is latency-bound (one row per wave and iteration)
+    while (nblk > 64 && (size_t)nblk * 2 * F * 2 + (size_t)8 * 2 * F > ws_floats) nblk /= 2;
     const size_t need = (size_t)nblk * 2 * F;
     OCRL_REQUIRE(need + (size_t)8 * 2 * F <= ws_floats, "layernorm bwd: workspace too small");
     dim3 grid(nblk), blk(256);
@@ -846,12 +929,14 @@ int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, fl
     return 0;
 }
 int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st) {
+    OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "softmax_bwd_rows: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
     hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, st, z, d, V, scale);
     OCRL_CHECK_LAUNCH("softmax_bwd_rows");
     return 0;
 }
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st) {
     OCRL_REQUIRE(ws_floats >= (size_t)R, "ce: workspace too small");
+    OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "ce: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
     hipLaunchKernelGGL(ce_kernel, dim3((unsigned)R), dim3(256), 0, st, pred, tokens, ws, V, 1.0f / B, write_grad);
     OCRL_CHECK_LAUNCH("ce");
     return reduce_partials_launch(ws, (int)R, out, 1.0f / B, 0, st);
