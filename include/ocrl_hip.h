@@ -33,6 +33,7 @@ typedef struct ocrl_slate_config {
     float dropout;                              /* ocr_config.learning.dropout */
     int max_batch;                              /* workspace is sized for this many images */
     int use_bcdec;                              /* ocr_config.use_bcdec: Slot-Attention configuration (broadcast decoder) */
+    int hard;                                   /* ocr_config.hard: straight-through Gumbel sample into the dVAE decoder */
 } ocrl_slate_config;
 
 int ocrl_slate_create(const ocrl_slate_config* cfg, ocrl_slate** out);

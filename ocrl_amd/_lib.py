@@ -11,7 +11,7 @@ _lib = None
 class SlateConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("obs_size", "obs_channels", "vocab_size", "d_model", "cnn_hidden", "num_slots",
                                       "num_iterations", "slot_size", "mlp_hidden", "num_dec_blocks", "num_dec_heads")] + \
-               [("dropout", c_float), ("max_batch", c_int), ("use_bcdec", c_int)]
+               [("dropout", c_float), ("max_batch", c_int), ("use_bcdec", c_int), ("hard", c_int)]
 
 
 class IodineConfig(ctypes.Structure):

@@ -264,7 +264,7 @@ __global__ void mse_kernel(const float* __restrict__ obs, const float* __restric
 __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __restrict__ raw, const float* __restrict__ e1,
                                                              const float* __restrict__ e2, float* __restrict__ z,
                                                              int* __restrict__ tokens, int V, float inv_tau,
-                                                             unsigned long long seed) {
+                                                             unsigned long long seed, float* __restrict__ zst) {
     __shared__ float red[4];
     __shared__ float redv[4];
     __shared__ int redi[4];
@@ -317,6 +317,34 @@ __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < GS_MAXPT; ++i)
         if (i < npt) z[row * V + i * 256 + threadIdx.x] = u[i] * inv;
+    if (zst) {
+        // hard=True (ocrs/common/utils.py:81-83): the dVAE decoder sees y_hard - y_soft.detach() + y_soft, evaluated in the
+        // reference's order; index = first maximum of y_soft (exp is monotone, so of u)
+        float b1 = -1.f;
+        int b1i = 0;
+#pragma unroll
+        for (int i = 0; i < GS_MAXPT; ++i)
+            if (i < npt && u[i] > b1) { b1 = u[i]; b1i = i * 256 + threadIdx.x; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(b1, o, 64);
+            const int oi = __shfl_xor(b1i, o, 64);
+            if (ob > b1 || (ob == b1 && oi < b1i)) { b1 = ob; b1i = oi; }
+        }
+        __shared__ float hv[4];
+        __shared__ int hi[4];
+        if ((threadIdx.x & 63) == 0) { hv[threadIdx.x >> 6] = b1; hi[threadIdx.x >> 6] = b1i; }
+        __syncthreads();
+        for (int k = 0; k < 4; ++k)
+            if (hv[k] > b1 || (hv[k] == b1 && hi[k] < b1i)) { b1 = hv[k]; b1i = hi[k]; }
+#pragma unroll
+        for (int i = 0; i < GS_MAXPT; ++i)
+            if (i < npt) {
+                const int v = i * 256 + threadIdx.x;
+                const float ys = u[i] * inv;
+                zst[row * V + v] = ((v == b1i ? 1.f : 0.f) - ys) + ys;
+            }
+    }
     // argmax (first index wins ties, like torch.argmax on CPU)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -921,10 +949,10 @@ int mse_launch(const float* obs, const float* recon, float* drecon, float* out, 
     return reduce_partials_launch(ws, nblk, out, 1.0f / B, 0, st);
 }
 int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, float* z, int* tokens, long long R, int V, float tau,
-                          unsigned long long seed, hipStream_t st) {
+                          unsigned long long seed, hipStream_t st, float* zst) {
     OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "gumbel_softmax: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
     OCRL_REQUIRE((e1 == nullptr) == (e2 == nullptr), "gumbel_softmax: give both noise tensors or none");
-    hipLaunchKernelGGL(gumbel_softmax_kernel, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed);
+    hipLaunchKernelGGL(gumbel_softmax_kernel, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed, zst);
     OCRL_CHECK_LAUNCH("gumbel_softmax");
     return 0;
 }

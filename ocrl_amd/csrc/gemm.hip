@@ -22,7 +22,9 @@ struct TileA {
     // KC: [BM][BK+4]   !KC: [BK][BM+4]
     static constexpr int LD = KC ? (BK + 4) : (BM + 4);
     static constexpr int ELEMS = KC ? BM * (BK + 4) : BK * (BM + 4);
-    static constexpr int NV = BM / 32;  // float4 per thread per k-tile
+    // float4 per thread per k-tile.  !KC: a k-row is BM/4 float4, 256/(BM/4) k-rows per pass (BM = 192: 5 rows, threads >= 240 idle)
+    static constexpr int F4 = BM / 4, RPP = 256 / F4;
+    static constexpr int NV = KC ? BM / 32 : (BK + RPP - 1) / RPP;
 };
 
 // global -> registers for one operand tile.  rows = extent along m (or n), base points at
@@ -46,7 +48,7 @@ __device__ inline float4 adrop_apply(float4 v, const ADrop& d, long long lrow, i
 // mn0 / k0: logical coordinates of the tile origin (only used for the dropout index)
 template <int BMN, bool KC, bool DROP>
 __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_valid, int k_valid,
-                                 float4 (&r)[BMN / 32], const ADrop& dr, int mn0, int k0) {
+                                 float4 (&r)[TileA<BMN, KC>::NV], const ADrop& dr, int mn0, int k0) {
     const int t = threadIdx.x;
     if (KC) {
         const int c4 = t & 7, r0 = t >> 3;
@@ -65,10 +67,10 @@ __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_v
         constexpr int RPP = 256 / F4;        // k-rows per pass
         const int c4 = t % F4, r0 = t / F4;
 #pragma unroll
-        for (int i = 0; i < BMN / 32; ++i) {
+        for (int i = 0; i < TileA<BMN, KC>::NV; ++i) {
             const int kr = r0 + RPP * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kr < k_valid && c4 * 4 < rows_valid) {
+            if (r0 < RPP && kr < BK && kr < k_valid && c4 * 4 < rows_valid) {
                 v = *reinterpret_cast<const float4*>(g + (size_t)kr * ld + c4 * 4);
                 if (DROP) v = adrop_apply(v, dr, k0 + kr, mn0 + c4 * 4);           // stored [k][m]: logical row = k
             }
@@ -78,7 +80,7 @@ __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_v
 }
 
 template <int BMN, bool KC>
-__device__ inline void store_tile(float* __restrict__ s, const float4 (&r)[BMN / 32]) {
+__device__ inline void store_tile(float* __restrict__ s, const float4 (&r)[TileA<BMN, KC>::NV]) {
     const int t = threadIdx.x;
     constexpr int LD = TileA<BMN, KC>::LD;
     if (KC) {
@@ -90,7 +92,8 @@ __device__ inline void store_tile(float* __restrict__ s, const float4 (&r)[BMN /
         constexpr int RPP = 256 / F4;
         const int c4 = t % F4, r0 = t / F4;
 #pragma unroll
-        for (int i = 0; i < BMN / 32; ++i) *reinterpret_cast<float4*>(s + (r0 + RPP * i) * LD + c4 * 4) = r[i];
+        for (int i = 0; i < TileA<BMN, KC>::NV; ++i)
+            if (r0 < RPP && r0 + RPP * i < BK) *reinterpret_cast<float4*>(s + (r0 + RPP * i) * LD + c4 * 4) = r[i];
     }
 }
 
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             for (int k = 0; k < BK; ++k) bsum += as[k * LD + threadIdx.x];
         }
     };
-    float4 ra[BM / 32], rb[BN / 32];
+    float4 ra[TileA<BM, AKC>::NV], rb[TileA<BN, BKC>::NV];
     if (SB) {
         // single LDS buffer (half the LDS -> twice the resident workgroups): next tile's global loads fly during compute
         if (kt0 < kt1) {
@@ -362,10 +365,14 @@ static int launch_tr(const GemmArgs& a, hipStream_t st) {
         case 128064: return launch_cfg<128, 64, AKC, BKC>(a, st);
         case 64128: return launch_cfg<64, 128, AKC, BKC>(a, st);
         case 64064: return launch_cfg<64, 64, AKC, BKC>(a, st);
+        case 128192: if (AKC) return launch_cfg<128, 192, AKC, BKC>(a, st); break;
         default: break;
     }
     // measured on MI355X (tools/bench_gemm.py): 128-wide column tiles only pay when N is a multiple of 128;
     // N = 192 / 64 (projections, weight gradients with 192 inputs) run 10-20 % faster on 128x64 tiles
+    // long-K activation x weight products with N = 192 (the model width), e.g. the vocabulary-head dX: one 128x192 tile reads A
+    // once and moves 38 FLOP per staged byte instead of 21 (+7 % measured at K = 4096; short K is faster on 128x64)
+    if (AKC && a.N == 192 && a.K >= 1024 && a.M >= 4096) return launch_cfg<128, 192, AKC, BKC>(a, st);
     const bool wide = (a.N % 128 == 0);
     if (wide) {
         if (a.M > 64) return launch_cfg<128, 128, AKC, BKC>(a, st);

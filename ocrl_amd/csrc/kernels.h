@@ -77,7 +77,7 @@ int colsum_launch(const float* X, long long ld, float* out, long long R, int F, 
 int reduce_partials_launch(const float* part, int n, float* out, float scale, int accumulate, hipStream_t st);
 int mse_launch(const float* obs, const float* recon, float* drecon, float* out, int B, int C, int H, int W, float* ws, size_t ws_floats, hipStream_t st);
 int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, float* z, int* tokens, long long R, int V, float tau,
-                          unsigned long long seed, hipStream_t st);
+                          unsigned long long seed, hipStream_t st, float* zst = nullptr);
 int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st);
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st);
 int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,

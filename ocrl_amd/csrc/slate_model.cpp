@@ -170,6 +170,7 @@ void SlateModel::layout_workspace(bool commit) {
     for (int i = 0; i < 7; ++i) de_[i] = carve(nullptr, BT * 64);
     zraw_ = carve("zraw", BT * V);
     z_ = carve("z", BT * V);
+    zdec_ = cfg.hard ? carve("z_st", BT * V) : z_;
     tokens_ = reinterpret_cast<int*>(carve("tokens", BT));
     dd0_ = carve(nullptr, BT * 64); dd1_ = carve(nullptr, BT * 64); dd2_ = carve(nullptr, BT * 64); dd3_ = carve(nullptr, BT * 64);
     dd4_ = carve(nullptr, BT * 256); ps1_ = carve(nullptr, BT * 256);
@@ -372,17 +373,18 @@ int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
     for (int i = 1; i < 7; ++i)
         RC(lin_fwd(de_[i - 1], 64, P(fmt("_dvae._encoder.%d.m.weight", i)), P(fmt("_dvae._encoder.%d.m.bias", i)), de_[i], 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
     RC(lin_fwd(de_[6], 64, P("_dvae._encoder.7.weight"), P("_dvae._encoder.7.bias"), zraw_, V, BT, V, 64, 0, nullptr, 0, 0.f, 0, st));
-    RC(gumbel_softmax_launch(zraw_, in.noise_z, in.noise_zh, z_, tokens_, BT, V, in.tau, in.seed, st));
+    RC(gumbel_softmax_launch(zraw_, in.noise_z, in.noise_zh, z_, tokens_, BT, V, in.tau, in.seed, st, cfg.hard ? zdec_ : nullptr));
     RC(dvae_decode(B, drecon_, st));
     return 0;
 }
 
 // dVAE decoder on z_ -> recon_ (ocrs/common/models.py:24-37,44-45) and the reconstruction loss into metrics[0]
-int SlateModel::dvae_decode(int B, float* drecon, hipStream_t st) {
+int SlateModel::dvae_decode(int B, float* drecon, hipStream_t st, const float* zin) {
+    if (!zin) zin = zdec_;
     const long long BT = (long long)B * T, BN = (long long)B * N;
     const int ch = cfg.obs_channels;
     // decoder
-    RC(lin_fwd(z_, V, P("_dvae._decoder.0.m.weight"), P("_dvae._decoder.0.m.bias"), dd0_, 64, BT, 64, V, 1, nullptr, 0, 0.f, 0, st));
+    RC(lin_fwd(zin, V, P("_dvae._decoder.0.m.weight"), P("_dvae._decoder.0.m.bias"), dd0_, 64, BT, 64, V, 1, nullptr, 0, 0.f, 0, st));
     RC(conv_layer_fwd(dd0_, dw_fwd_[0], P("_dvae._decoder.1.m.bias"), dd1_, B, E, E, 3, 64, 1, nullptr, nullptr, st));
     RC(lin_fwd(dd1_, 64, P("_dvae._decoder.2.m.weight"), P("_dvae._decoder.2.m.bias"), dd2_, 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
     RC(lin_fwd(dd2_, 64, P("_dvae._decoder.3.m.weight"), P("_dvae._decoder.3.m.bias"), dd3_, 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
@@ -493,7 +495,7 @@ int SlateModel::generate(hipStream_t st) {
         RC(argmax_pos_launch(pred_, tokens_, B, T, V, t, st));
     }
     RC(onehot_launch(tokens_, z_, (long long)B * T, V, st));
-    RC(dvae_decode(B, nullptr, st));
+    RC(dvae_decode(B, nullptr, st, z_));
     return 0;
 }
 
@@ -657,7 +659,7 @@ int SlateModel::bwd_dvae(hipStream_t st) {
     RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.2.m.weight"), gdB_, 64, BT, 64, 64, dd1_, 64, nullptr, 0, st));       // gdB = d dd1 (pre-relu)
     RC(conv_layer_wgrad(dd0_, gdB_, G("_dvae._decoder.1.m.weight"), G("_dvae._decoder.1.m.bias"), B, E, E, 3, 64, 64, st));
     RC(conv_layer_fwd(gdB_, dw_bwd_[0], nullptr, gdA_, B, E, E, 3, 64, 0, nullptr, dd0_, st));                     // gdA = d dd0 (pre-relu)
-    RC(lin_bwd_w(gdA_, 64, z_, V, G("_dvae._decoder.0.m.weight"), G("_dvae._decoder.0.m.bias"), BT, 64, V, 1.f, st));
+    RC(lin_bwd_w(gdA_, 64, zdec_, V, G("_dvae._decoder.0.m.weight"), G("_dvae._decoder.0.m.bias"), BT, 64, V, 1.f, st));
     float* dz = pred_;      // the [BT,V] buffer is free again (decoder backward ran first)
     RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.0.m.weight"), dz, V, BT, 64, V, nullptr, 0, nullptr, 0, st));
     // ---- Gumbel softmax + log_softmax backward (row sums of the soft-max gradient vanish, so d raw = d logp)

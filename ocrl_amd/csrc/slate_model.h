@@ -14,6 +14,7 @@ struct SlateConfig {
     float dropout = 0.1f;
     int max_batch = 1;
     int use_bcdec = 0;      // Slot-Attention configuration: spatial-broadcast decoder instead of dVAE + transformer
+    int hard = 0;           // ocr_config.hard: straight-through Gumbel sample for the dVAE decoder (utils.py:81-83)
 };
 
 struct ParamInfo {
@@ -77,7 +78,7 @@ private:
     int fwd_encoder(const StepInputs& in, hipStream_t st);
     int fwd_dvae(const StepInputs& in, hipStream_t st);
     int fwd_decoder(hipStream_t st, bool with_ce = true);
-    int dvae_decode(int B, float* drecon, hipStream_t st);
+    int dvae_decode(int B, float* drecon, hipStream_t st, const float* zin = nullptr);
     int bwd_decoder(hipStream_t st);
     int bwd_encoder(hipStream_t st);
     int bwd_dvae(hipStream_t st);
@@ -106,7 +107,7 @@ private:
     // ---- workspace tensors
     float *scratch_ = nullptr;            // transient: split-k slabs, column-sum partials, wgrad slabs
     size_t scratch_floats_ = 0;
-    float *obs8_, *patches_, *de_[7], *zraw_, *z_;
+    float *obs8_, *patches_, *de_[7], *zraw_, *z_, *zdec_;      // zdec_: what the dVAE decoder consumes (z_ or its straight-through form)
     int* tokens_;
     float *dd0_, *dd1_, *dd2_, *dd3_, *dd4_, *ps1_, *dd6_, *dd7_, *dd8_, *dd9_, *ps2_, *recon_, *drecon_;
     float *e1_, *e2_, *e3_, *e4_, *posmap_, *gridT_, *ln0_, *ln0_mean_, *ln0_rstd_, *h1_, *x_;

@@ -33,7 +33,8 @@ class SlateEngine:
         self.max_batch = int(max_batch)
         c = _lib.SlateConfig(dims.obs_size, dims.obs_channels, dims.vocab_size, dims.d_model, dims.cnn_hidden, dims.num_slots,
                              dims.num_iterations, dims.slot_size, dims.mlp_hidden, dims.num_dec_blocks, dims.num_dec_heads,
-                             float(dims.dropout), self.max_batch, int(bool(getattr(dims, "use_bcdec", False))))
+                             float(dims.dropout), self.max_batch, int(bool(getattr(dims, "use_bcdec", False))),
+                             int(bool(getattr(dims, "hard", False))))
         h = ctypes.c_void_p()
         _lib.check(self.L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)))
         self.h = h

@@ -45,7 +45,7 @@ def _dims(ocr_config, env_config):
         num_slots=int(sa.num_slots), num_iterations=int(sa.num_iterations), slot_size=int(sa.slot_size),
         mlp_hidden=int(sa.mlp_hidden_size), num_dec_blocks=int(ocr_config.tfdec.num_dec_blocks),
         num_dec_heads=int(ocr_config.tfdec.num_dec_heads), dropout=float(ocr_config.learning.dropout),
-        use_bcdec=bool(ocr_config.use_bcdec))
+        use_bcdec=bool(ocr_config.use_bcdec), hard=bool(ocr_config.hard))
 
 
 def _position_grid(S):
@@ -105,8 +105,6 @@ class SLATE_Module(nn.Module):
         self._tau_start, self._tau_final, self._tau_steps = ocr_config.tau_start, ocr_config.tau_final, ocr_config.tau_steps
         self._tau = 1.0
         self._hard = bool(ocr_config.hard)
-        if self._hard:
-            raise NotImplementedError("ocr.hard=True is not supported by the HIP backend (reference default is False)")
         if self._use_cnn_feat:            # slate_module.py:87-92
             self.num_slots = self._obs_size ** 2
             self.rep_dim = self._dims.cnn_hidden + self._obs_channels
@@ -142,7 +140,7 @@ class SLATE_Module(nn.Module):
         L = _lib.lib()
         d = self._dims
         c = _lib.SlateConfig(d.obs_size, d.obs_channels, d.vocab_size, d.d_model, d.cnn_hidden, d.num_slots, d.num_iterations,
-                             d.slot_size, d.mlp_hidden, d.num_dec_blocks, d.num_dec_heads, d.dropout, 1, int(d.use_bcdec))
+                             d.slot_size, d.mlp_hidden, d.num_dec_blocks, d.num_dec_heads, d.dropout, 1, int(d.use_bcdec), int(d.hard))
         h = ctypes.c_void_p()
         _lib.check(L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)))
         out = []
@@ -308,7 +306,7 @@ class SLATE_Module(nn.Module):
             if self._use_bcdec:
                 raise NotImplementedError("with_rep is not available with use_bcdec on the HIP backend (the dVAE forward is skipped)")
             E, V = self._enc_size, self._vocab_size
-            z = self.engine.tensor("z", (B, E, E, V)).permute(0, 3, 1, 2)
+            z = self.engine.tensor("z_st" if self._hard else "z", (B, E, E, V)).permute(0, 3, 1, 2)
             return metrics, z
         return metrics
 

@@ -29,7 +29,7 @@ def dims_from_cfg(cfg):
     return SimpleNamespace(obs_size=cfg.obs_size, obs_channels=cfg.obs_channels, vocab_size=cfg.vocab_size, d_model=cfg.d_model,
                            cnn_hidden=cfg.cnn_hidden, num_slots=cfg.num_slots, num_iterations=cfg.num_iterations,
                            slot_size=cfg.slot_size, mlp_hidden=cfg.mlp_hidden, num_dec_blocks=cfg.num_dec_blocks,
-                           num_dec_heads=cfg.num_dec_heads, dropout=cfg.dropout, use_bcdec=cfg.use_bcdec)
+                           num_dec_heads=cfg.num_dec_heads, dropout=cfg.dropout, use_bcdec=cfg.use_bcdec, hard=cfg.hard)
 
 
 def load_params(engine, P):

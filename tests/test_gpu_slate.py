@@ -16,6 +16,7 @@ MID = dict(obs_size=32, vocab_size=512, num_slots=5, num_iterations=2, num_dec_b
 LONG = dict(obs_size=64, vocab_size=256, num_slots=4, num_iterations=1, num_dec_blocks=1)     # T = 256: four causal key tiles
 K16 = dict(obs_size=16, vocab_size=256, num_slots=16, num_iterations=2, num_dec_blocks=1)     # BASELINE config 5's slot count (two slot blocks)
 K11 = dict(obs_size=16, vocab_size=256, num_slots=11, num_iterations=2, num_dec_blocks=1)     # uneven slot blocks (6 + 5)
+HARD = dict(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, hard=True)   # straight-through dVAE sample
 
 
 def make_engine(cfg, B):
@@ -51,7 +52,7 @@ def compare_forward(tag, eng, cfg, res, B):
     errs = {}
     zl = torch.log_softmax(eng.tensor("zraw", (B, T, V)).cpu(), -1)
     errs["z_logits"] = relerr(zl, res["z_logits"].permute(0, 2, 3, 1).reshape(B, T, V))
-    errs["z"] = relerr(eng.tensor("z", (B, T, V)), res["z"].permute(0, 2, 3, 1).reshape(B, T, V))
+    errs["z"] = relerr(eng.tensor("z_st" if cfg.hard else "z", (B, T, V)), res["z"].permute(0, 2, 3, 1).reshape(B, T, V))
     tok = eng.tensor("tokens", (B, T), torch.int32).cpu().long()
     errs["tokens_mismatch"] = float((tok != res["tokens"]).sum().item())
     errs["recon"] = relerr(eng.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2), res["recon"])
@@ -80,7 +81,7 @@ def compare_grads(tag, eng, trainer):
     return worst, rows
 
 
-@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2)])
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2), ("hard", HARD, 2)])
 def test_forward_backward_eval(tag, over, B):
     """dropout off: every stage of the forward, then every parameter gradient"""
     cfg = O.default_cfg(**over)
