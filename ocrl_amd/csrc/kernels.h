@@ -37,6 +37,7 @@ struct GemmArgs {
     float adrop_p = 0.f; unsigned adrop_site = 0; int adrop_ld = 0;
     // fused bias gradient for the dW form (akc == 0): bias_out[m] = sum_k A(m,k)  (partials per split at stride sBias)
     float* bias_out = nullptr; long long sBias = 0;
+    int diag = 0;                         // development diagnostic (OCRL_GEMM_DIAG): wrong results, timing only
 };
 int gemm_launch(const GemmArgs& a, hipStream_t st);
 int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
