@@ -32,12 +32,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ inline float red16_sum(float v) {          // over the 16 lanes sharing lane>>4
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+// All-reduce over the 16 lanes sharing lane>>4 (one DPP row) by row rotations 8, 4, 2, 1: VALU-speed DPP moves, no trip
+// through the LDS crossbar (ds_bpermute), which is what __shfl_xor costs.
+#define SA_ROR(v, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x120 + (n), 0xF, 0xF, false))
+__device__ inline float red16_sum(float v) {
+    v += SA_ROR(v, 8); v += SA_ROR(v, 4); v += SA_ROR(v, 2); v += SA_ROR(v, 1);
     return v;
 }
 __device__ inline float red16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, SA_ROR(v, 8)); v = fmaxf(v, SA_ROR(v, 4)); v = fmaxf(v, SA_ROR(v, 2)); v = fmaxf(v, SA_ROR(v, 1));
     return v;
 }
 __device__ inline float redg_sum(float v) {           // over the 4 lanes of one position (same lane & 15)
@@ -45,56 +48,61 @@ __device__ inline float redg_sum(float v) {           // over the 4 lanes of one
     return v;
 }
 
-// out[j][col] = scale * sum_e in[j][e] * Wt[e*ldw + col] + bias[col],  col < NC, j < K   (in/out in LDS).
-// Thread = (E-slice g, column): the reduction over e is split over blockDim/NC thread groups and combined through
-// `scr` ([G][K][NC] floats) in a fixed order.  Ends with a workgroup barrier.
+// out[j][col] = scale * sum_e in[j][e] * Wt[e*ldw + col] + bias[col],  col < NC, j < K   (in/out in LDS; E % 4 == 0, rows 16-byte aligned).
+// Thread = (E-slice g, column): the reduction over e is split over blockDim/NC thread groups (contiguous slices) and combined
+// through `scr` ([G][K][NC] floats) in a fixed order.  Per 4 values of e a thread issues 4 weight loads (L2) and K broadcast
+// ds_read_b128 of the inputs — one LDS instruction per 4 FMAs instead of one per FMA.  Ends with a workgroup barrier.
 template <int K>
-__device__ __forceinline__ void matvec(const float* __restrict__ Wt, int ldw, int E, int NC, const float* in, int ldin,
-                                    float* out, int ldout, const float* __restrict__ bias, float scale, float* scr) {
+__device__ __forceinline__ void matvec(const float* __restrict__ Wt, int ldw, int E, int NC, const float* in, int ldin, float* out, int ldout,
+                                       const float* __restrict__ bias, float scale, float* scr) {
     const int nt = blockDim.x, tid = threadIdx.x;
     const int ncp = (NC + 63) & ~63;
     int G = nt / ncp;
     if (G > 16) G = 16;
-    if (G <= 1) {
-        for (int col = tid; col < NC; col += nt) {
-            float acc[K];
+    if (G < 1) G = 1;
+    const int EB = (((E + G - 1) / G) + 3) & ~3;          // slice length, multiple of 4
+    const int ncols = G > 1 ? 1 : (NC + nt - 1) / nt;     // G == 1: a thread may own several columns
+    for (int cc = 0; cc < ncols; ++cc) {
+        const int g = G > 1 ? tid / ncp : 0;
+        const int col = G > 1 ? tid - g * ncp : tid + cc * nt;
+        const bool act = g < G && col < NC;
+        float acc[K];
 #pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] = 0.f;
-#pragma unroll 4
-            for (int e = 0; e < E; ++e) {
-                const float w = Wt[e * ldw + col];
+        for (int j = 0; j < K; ++j) acc[j] = 0.f;
+        if (act) {
+            const int e0 = g * EB, e1 = (e0 + EB < E) ? e0 + EB : E;
+            const float* wp = Wt + (size_t)e0 * ldw + col;
+#pragma unroll 2
+            for (int e = e0; e < e1; e += 4, wp += 4 * (size_t)ldw) {
+                const float w0 = wp[0], w1 = wp[ldw], w2 = wp[2 * (size_t)ldw], w3 = wp[3 * (size_t)ldw];
 #pragma unroll
-                for (int j = 0; j < K; ++j) acc[j] += in[j * ldin + e] * w;
+                for (int j = 0; j < K; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(in + j * ldin + e);
+                    acc[j] += v.x * w0 + v.y * w1 + v.z * w2 + v.w * w3;
+                }
             }
+        }
+        if (G > 1) {
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) scr[(g * K + j) * NC + col] = acc[j];
+            }
+        } else if (act) {
             const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int j = 0; j < K; ++j) out[j * ldout + col] = acc[j] * scale + bv;
         }
-        __syncthreads();
-        return;
     }
-    const int g = tid / ncp, col = tid - g * ncp;
-    if (g < G && col < NC) {
-        float acc[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] = 0.f;
-#pragma unroll 4
-        for (int e = g; e < E; e += G) {
-            const float w = Wt[e * ldw + col];
-#pragma unroll
-            for (int j = 0; j < K; ++j) acc[j] += in[j * ldin + e] * w;
+    __syncthreads();
+    if (G > 1) {
+        for (int i = tid; i < K * NC; i += nt) {
+            const int j = i / NC, c = i - j * NC;
+            float s = 0.f;
+            for (int w = 0; w < G; ++w) s += scr[(w * K + j) * NC + c];
+            out[j * ldout + c] = s * scale + (bias ? bias[c] : 0.f);
         }
-#pragma unroll
-        for (int j = 0; j < K; ++j) scr[(g * K + j) * NC + col] = acc[j];
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = tid; i < K * NC; i += nt) {
-        const int j = i / NC, c = i - j * NC;
-        float s = 0.f;
-        for (int w = 0; w < G; ++w) s += scr[(w * K + j) * NC + c];
-        out[j * ldout + c] = s * scale + (bias ? bias[c] : 0.f);
-    }
-    __syncthreads();
 }
 
 // LayerNorm of K rows of width D held in LDS (one wave per row).
@@ -197,13 +205,14 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
     for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
     const int ntile = (N + 15) / 16;
-    float4 cur[4];
-    if (wv < ntile) sa_load_tile(xb, N, wv, li, g, cur);
-#pragma unroll 1
-    for (int t = wv; t < ntile; t += nw) {
+    // two register stages per wave: while tile t is processed, tiles t + nw and t + 2 nw are in flight
+    float4 bufA[4], bufB[4];
+    if (wv < ntile) sa_load_tile(xb, N, wv, li, g, bufA);
+    if (wv + nw < ntile) sa_load_tile(xb, N, wv + nw, li, g, bufB);
+    auto tile_step = [&](float4 (&cur)[4], int t) {
         float xn[16];
         sa_ln16(cur, xn);
-        if (t + nw < ntile) sa_load_tile(xb, N, t + nw, li, g, cur);      // in flight during the MFMA / softmax phase
+        if (t + 2 * nw < ntile) sa_load_tile(xb, N, t + 2 * nw, li, g, cur);
         f32x4_t L = (f32x4_t){l0, l0, l0, l0};
 #pragma unroll
         for (int k = 0; k < 16; ++k) L = MFMA16(xn[k], qpr[k], L);           // L[r] = logits[pos 4g+r][slot li]
@@ -229,6 +238,11 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = MFMA16(tile[(4 * g + r) * SA_TLD + 16 * m + li], w[r], acc[m]);   // sum_n w xn^T: [ch][slot]
         __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll 1
+    for (int t = wv; t < ntile; t += 2 * nw) {
+        tile_step(bufA, t);
+        if (t + nw < ntile) tile_step(bufB, t + nw);
     }
     csum = redg_sum(csum);
     __syncthreads();          // every wave is done with its tile: the region is reused for the partials
@@ -399,6 +413,13 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
         if (t + nw < ntile) sa_load_tile(xb, N, t + nw, li, g, nxt);
         float xn[16];
         const float rs = sa_ln16(cur, xn);
+        // the running d xn of this tile (earlier iterations) is fetched now and added after the tile's 64 MFMAs
+        float4 od[4];
+        if (!FIRST) {
+            const int pos0 = t * 16 + li;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) od[c] = pos0 < N ? dxb[pos0 * 16 + 4 * c + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         f32x4_t L = (f32x4_t){l0, l0, l0, l0}, DA = (f32x4_t){d0, d0, d0, d0};
 #pragma unroll
         for (int k = 0; k < 16; ++k) { L = MFMA16(xn[k], qpr[k], L); DA = MFMA16(xn[k], dur[k], DA); }
@@ -449,12 +470,9 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
         }
         __builtin_amdgcn_wave_barrier();
         const int pos = t * 16 + li;
-        if (!FIRST && pos < N) {
+        if (!FIRST) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 o = dxb[pos * 16 + 4 * c + g];
-                dv[4 * c] += o.x; dv[4 * c + 1] += o.y; dv[4 * c + 2] += o.z; dv[4 * c + 3] += o.w;
-            }
+            for (int c = 0; c < 4; ++c) { dv[4 * c] += od[c].x; dv[4 * c + 1] += od[c].y; dv[4 * c + 2] += od[c].z; dv[4 * c + 3] += od[c].w; }
         }
         if (FINAL) {      // LayerNorm(norm_inputs) backward from d xn, in the load layout
             float m1 = 0.f, m2 = 0.f;
