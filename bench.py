@@ -206,9 +206,9 @@ def main():
     conv_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if cnt[0] else 0.0
     traffic = None       # HBM bytes per launch from committed rocprofv3 PMC passes (same kernel, same shape), if present
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")))
         if B == 128 and S == 128:
-            traffic = tj["kernels"]["conv_fwd_kernel<5, 64, 64>"]["hbm_bytes_per_launch"]
+            traffic = tj["kernels"]["void conv_fwd_kernel<5, 64, 64>(ConvArgs)"]["hbm_bytes_per_launch"]
     except Exception:
         pass
     out = {

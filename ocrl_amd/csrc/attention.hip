@@ -165,22 +165,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
-// delta[b,h,q] = sum_dim dO[q,dim] * O[q,dim]   (one thread per (row, head))
-__global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta, long long BT, int T, int d, int h) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BT * h) return;
-    const int hd = i % h;
-    const long long row = i / h;
-    const int dh = d / h;
-    const float* a = dO + row * d + hd * dh;
-    const float* c = O + row * d + hd * dh;
+// delta[b,h,q] = sum_dim dO[q,dim] * O[q,dim].  A row's d/4 float4 are read by d/4 consecutive threads (full cache lines);
+// the per-head sums go through LDS.  RPB rows per 256-thread block.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ delta, long long BT, int T, int d,
+                                                         int h) {
+    __shared__ float part[256];
+    const int F4 = d >> 2, RPB = 256 / F4, HF = F4 / h;            // float4 per row, rows per block, float4 per head
+    const int rl = threadIdx.x / F4, c4 = threadIdx.x - rl * F4;
+    const long long row = (long long)blockIdx.x * RPB + rl;
     float s = 0.f;
-    for (int k = 0; k < dh; k += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(a + k), y = *reinterpret_cast<const float4*>(c + k);
-        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    if (rl < RPB && row < BT) {
+        const float4 x = *reinterpret_cast<const float4*>(dO + row * d + c4 * 4), y = *reinterpret_cast<const float4*>(O + row * d + c4 * 4);
+        s = x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
     }
-    const long long b = row / T, q = row % T;
-    delta[(b * h + hd) * T + q] = s;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < RPB * h) {
+        const int r2 = threadIdx.x / h, hd = threadIdx.x - r2 * h;
+        const long long row2 = (long long)blockIdx.x * RPB + r2;
+        if (row2 < BT) {
+            float t = 0.f;
+            for (int k = 0; k < HF; ++k) t += part[r2 * F4 + hd * HF + k];
+            const long long bb = row2 / T, q = row2 % T;
+            delta[(bb * h + hd) * T + q] = t;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------- backward: dK, dV
@@ -401,7 +410,8 @@ static int attn_launch_dh(const AttnArgs& a, int mode, hipStream_t st) {
         OCRL_CHECK_LAUNCH("attn_fwd");
     } else {
         const long long BT = (long long)a.B * a.T;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(BT * a.h, 256)), dim3(256), 0, st, a.dO, a.o, a.delta, BT, a.T, a.d, a.h);
+        OCRL_REQUIRE(a.d % 4 == 0 && a.d <= 1024 && (a.d / 4) % a.h == 0, "attention: d must be a multiple of 4*h, <= 1024");
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(BT, 256 / (a.d / 4))), dim3(256), 0, st, a.dO, a.o, a.delta, BT, a.T, a.d, a.h);
         OCRL_CHECK_LAUNCH("attn_delta");
         hipLaunchKernelGGL((attn_bwd_kv_kernel<DH>), grid, blk, 0, st, a);
         OCRL_CHECK_LAUNCH("attn_bwd_kv");

@@ -806,19 +806,29 @@ __global__ void slot_init_kernel(const float* __restrict__ mu, const float* __re
     const int c = i % D;
     slots0[i] = mu[c] + __expf(logsig[c]) * slot_eps(noise, i, seed);
 }
-// one thread per column: dmu[c] = sum_r d[r][c]; dlogsig[c] = sum_r d[r][c] * exp(logsig[c]) * eps[r][c]
-__global__ void slot_init_bwd_kernel(const float* __restrict__ d, const float* __restrict__ logsig, const float* __restrict__ noise,
-                                     float* __restrict__ dmu, float* __restrict__ dlogsig, int R, int D, unsigned long long seed) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= D) return;
+// dmu[c] = sum_r d[r][c]; dlogsig[c] = sum_r d[r][c] * exp(logsig[c]) * eps[r][c].  One block per 64 columns: 16 row lanes per
+// column run in parallel and are combined through LDS (deterministic order).
+__global__ __launch_bounds__(1024) void slot_init_bwd_kernel(const float* __restrict__ d, const float* __restrict__ logsig, const float* __restrict__ noise,
+                                                             float* __restrict__ dmu, float* __restrict__ dlogsig, int R, int D, unsigned long long seed) {
+    __shared__ float ra[16][64], rb[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float g = d[(size_t)r * D + c];
-        a += g;
-        b += g * slot_eps(noise, (long long)r * D + c, seed);
+    if (c < D)
+        for (int r = rl; r < R; r += 16) {
+            const float g = d[(size_t)r * D + c];
+            a += g;
+            b += g * slot_eps(noise, (long long)r * D + c, seed);
+        }
+    ra[rl][cl] = a; rb[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { sa += ra[k][cl]; sb += rb[k][cl]; }
+        dmu[c] = sa;
+        dlogsig[c] = sb * __expf(logsig[c]);
     }
-    dmu[c] = a;
-    dlogsig[c] = b * __expf(logsig[c]);
 }
 __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1066,7 +1076,7 @@ int slot_init_launch(const float* mu, const float* logsig, const float* noise, f
     return 0;
 }
 int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float* noise, float* dmu, float* dlogsig, int BK, int D, unsigned long long seed, hipStream_t st) {
-    hipLaunchKernelGGL(slot_init_bwd_kernel, GRID1D(D), 0, st, dslots0, logsig, noise, dmu, dlogsig, BK, D, seed);
+    hipLaunchKernelGGL(slot_init_bwd_kernel, dim3(cdiv(D, 64)), dim3(1024), 0, st, dslots0, logsig, noise, dmu, dlogsig, BK, D, seed);
     OCRL_CHECK_LAUNCH("slot_init_bwd");
     return 0;
 }
