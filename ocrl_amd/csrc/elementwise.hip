@@ -261,6 +261,7 @@ __global__ void mse_kernel(const float* __restrict__ obs, const float* __restric
 // One workgroup per row of V logits.  logp = log_softmax(raw); z = softmax((logp + g1)/tau);
 // tok = argmax(logp + g2);  g = -log(e + tiny), e ~ Exp(1) injected (e1/e2) or drawn on device.
 #define GS_MAXPT 16
+template <int NPT>      // values per thread = V / 256 (compile-time for the common vocabulary sizes: no per-value guards); 0 = runtime
 __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __restrict__ raw, const float* __restrict__ e1,
                                                              const float* __restrict__ e2, float* __restrict__ z,
                                                              int* __restrict__ tokens, int V, float inv_tau,
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __rest
     __shared__ int redi[4];
     const long long row = blockIdx.x;
     const float* r = raw + row * V;
-    const int npt = V / 256;     // V % 256 == 0, V <= 4096
+    const int npt = NPT ? NPT : V / 256;     // V % 256 == 0, V <= 4096
     float x[GS_MAXPT];
     float mx = -INFINITY;
 #pragma unroll
@@ -363,10 +364,11 @@ __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __rest
 }
 
 // in place: d[v] = z[v] * (d[v] - sum_v z*d) * scale     (softmax backward for one row of V)
+template <int NPT>
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ z, float* __restrict__ d, int V, float scale) {
     __shared__ float red[4];
     const long long row = blockIdx.x;
-    const int npt = V / 256;                 // V % 256 == 0, V <= 256 * GS_MAXPT: one read of z and d, one write
+    const int npt = NPT ? NPT : V / 256;                 // V % 256 == 0, V <= 256 * GS_MAXPT: one read of z and d, one write
     float zz[GS_MAXPT], dd[GS_MAXPT];
     float s = 0.f;
 #pragma unroll
@@ -384,13 +386,14 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
 
 // cross entropy with hard targets, one workgroup per row: part[row] = lse - pred[tok];
 // pred <- (softmax(pred) - onehot(tok)) * inv_b   (in place gradient)
+template <int NPT>
 __global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ pred, const int* __restrict__ tokens, float* __restrict__ part,
                                                  int V, float inv_b, int write_grad) {
     __shared__ float red[4];
     const long long row = blockIdx.x;
     float* r = pred + row * V;
     const int tok = tokens[row];
-    const int npt = V / 256;                 // V % 256 == 0, V <= 256 * GS_MAXPT: the row lives in registers (one read, one exp, one write)
+    const int npt = NPT ? NPT : V / 256;                 // V % 256 == 0, V <= 256 * GS_MAXPT: the row lives in registers (one read, one exp, one write)
     float x[GS_MAXPT];
     float mx = -INFINITY, rt = 0.f;
 #pragma unroll
@@ -962,20 +965,26 @@ int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, fl
                           unsigned long long seed, hipStream_t st, float* zst) {
     OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "gumbel_softmax: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
     OCRL_REQUIRE((e1 == nullptr) == (e2 == nullptr), "gumbel_softmax: give both noise tensors or none");
-    hipLaunchKernelGGL(gumbel_softmax_kernel, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed, zst);
+    switch (V / 256) {
+        case 16: hipLaunchKernelGGL(gumbel_softmax_kernel<16>, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed, zst); break;
+        case 8: hipLaunchKernelGGL(gumbel_softmax_kernel<8>, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed, zst); break;
+        default: hipLaunchKernelGGL(gumbel_softmax_kernel<0>, dim3((unsigned)R), dim3(256), 0, st, raw, e1, e2, z, tokens, V, 1.0f / tau, seed, zst); break;
+    }
     OCRL_CHECK_LAUNCH("gumbel_softmax");
     return 0;
 }
 int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st) {
     OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "softmax_bwd_rows: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
-    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)R), dim3(256), 0, st, z, d, V, scale);
+    if (V == 4096) hipLaunchKernelGGL(softmax_bwd_rows_kernel<16>, dim3((unsigned)R), dim3(256), 0, st, z, d, V, scale);
+    else hipLaunchKernelGGL(softmax_bwd_rows_kernel<0>, dim3((unsigned)R), dim3(256), 0, st, z, d, V, scale);
     OCRL_CHECK_LAUNCH("softmax_bwd_rows");
     return 0;
 }
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st) {
     OCRL_REQUIRE(ws_floats >= (size_t)R, "ce: workspace too small");
     OCRL_REQUIRE(V % 256 == 0 && V <= 256 * GS_MAXPT, "ce: V must be a multiple of 256, <= %d", 256 * GS_MAXPT);
-    hipLaunchKernelGGL(ce_kernel, dim3((unsigned)R), dim3(256), 0, st, pred, tokens, ws, V, 1.0f / B, write_grad);
+    if (V == 4096) hipLaunchKernelGGL(ce_kernel<16>, dim3((unsigned)R), dim3(256), 0, st, pred, tokens, ws, V, 1.0f / B, write_grad);
+    else hipLaunchKernelGGL(ce_kernel<0>, dim3((unsigned)R), dim3(256), 0, st, pred, tokens, ws, V, 1.0f / B, write_grad);
     OCRL_CHECK_LAUNCH("ce");
     return reduce_partials_launch(ws, (int)R, out, 1.0f / B, 0, st);
 }
