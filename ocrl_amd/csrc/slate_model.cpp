@@ -3,6 +3,9 @@
 // Base.update (ocrs/base.py:60-74); maths restated in SURVEY.md Appendix A.
 #include "slate_model.h"
 
+#include <stdlib.h>
+#include <utility>
+
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -130,6 +133,7 @@ void SlateModel::layout_workspace(bool commit) {
         scratch_floats_ = need + (1 << 20);
     }
     scratch_ = carve(nullptr, scratch_floats_);
+    scratch2_ = cfg.use_bcdec ? scratch_ : carve(nullptr, scratch_floats_);
     obs8_ = carve("obs8", BN * 8);
     e1_ = carve(nullptr, BN * 64); e2_ = carve(nullptr, BN * 64); e3_ = carve(nullptr, BN * 64); e4_ = carve("feats", BN * 64);
     posmap_ = carve(nullptr, (size_t)N * C); gridT_ = carve(nullptr, (size_t)N * 4);
@@ -214,6 +218,16 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     ws_ = static_cast<char*>(ws);
     named_.clear();
     layout_workspace(true);
+    if (!side_) {
+        // OCRL_OVERLAP=1: +2.7 % images/s at config A, but kernels of the two branches then share the GPU and per-kernel timings
+        // (bench.py's roofline line, rocprofv3 durations) stop being comparable; off by default
+        const char* e = getenv("OCRL_OVERLAP");
+        if (e && atoi(e)) {
+            OCRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+            OCRL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+            OCRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        }
+    }
     // static tables
     RC(posgrid_launch(gridT_, S, 0));
     RC(fill_launch(recon_, (long long)Bmax * N * 4, 0.f, 0));
@@ -459,8 +473,20 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
         have_fwd_ = true;
         return 0;
     }
-    RC(fwd_dvae(in, st));
-    RC(fwd_encoder(in, st));
+    // the dVAE branch (tokens, reconstruction loss) and the CNN encoder + slot attention are independent until the decoder:
+    // the dVAE runs on the side stream, filling the CUs the one-workgroup-per-image slot-attention kernel leaves idle
+    if (side_) {
+        RC(fork_side(st));
+        std::swap(scratch_, scratch2_);
+        const int rc = fwd_dvae(in, side_);
+        std::swap(scratch_, scratch2_);
+        RC(rc);
+        RC(fwd_encoder(in, st));
+        RC(join_side(st));
+    } else {
+        RC(fwd_dvae(in, st));
+        RC(fwd_encoder(in, st));
+    }
     RC(fwd_decoder(st));
     RC(copy_launch(metrics_ + 0, metrics_ + 2, 1, st));
     RC(axpy_launch(metrics_ + 1, metrics_ + 2, 1, 1.f, st));      // loss = dvae_mse + cross_entropy
@@ -660,7 +686,7 @@ int SlateModel::bwd_dvae(hipStream_t st) {
     RC(conv_layer_wgrad(dd0_, gdB_, G("_dvae._decoder.1.m.weight"), G("_dvae._decoder.1.m.bias"), B, E, E, 3, 64, 64, st));
     RC(conv_layer_fwd(gdB_, dw_bwd_[0], nullptr, gdA_, B, E, E, 3, 64, 0, nullptr, dd0_, st));                     // gdA = d dd0 (pre-relu)
     RC(lin_bwd_w(gdA_, 64, zdec_, V, G("_dvae._decoder.0.m.weight"), G("_dvae._decoder.0.m.bias"), BT, 64, V, 1.f, st));
-    float* dz = pred_;      // the [BT,V] buffer is free again (decoder backward ran first)
+    float* dz = zraw_;      // the logits are not needed any more: d raw = d logp is built in their place
     RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.0.m.weight"), dz, V, BT, 64, V, nullptr, 0, nullptr, 0, st));
     // ---- Gumbel softmax + log_softmax backward (row sums of the soft-max gradient vanish, so d raw = d logp)
     RC(softmax_bwd_rows_launch(z_, dz, BT, V, 1.0f / last_.tau, st));
@@ -688,10 +714,32 @@ int SlateModel::backward(hipStream_t st) {
         have_fwd_ = false;
         return 0;
     }
-    RC(bwd_decoder(st));
-    RC(bwd_encoder(st));
-    RC(bwd_dvae(st));
+    if (side_) {         // the dVAE backward only needs the forward's reconstruction gradient: it overlaps decoder + encoder
+        RC(fork_side(st));
+        std::swap(scratch_, scratch2_);
+        const int rc = bwd_dvae(side_);
+        std::swap(scratch_, scratch2_);
+        RC(rc);
+        RC(bwd_decoder(st));
+        RC(bwd_encoder(st));
+        RC(join_side(st));
+    } else {
+        RC(bwd_decoder(st));
+        RC(bwd_encoder(st));
+        RC(bwd_dvae(st));
+    }
     have_fwd_ = false;
+    return 0;
+}
+
+int SlateModel::fork_side(hipStream_t st) {
+    OCRL_HIP(hipEventRecord(ev_fork_, st));
+    OCRL_HIP(hipStreamWaitEvent(side_, ev_fork_, 0));
+    return 0;
+}
+int SlateModel::join_side(hipStream_t st) {
+    OCRL_HIP(hipEventRecord(ev_join_, side_));
+    OCRL_HIP(hipStreamWaitEvent(st, ev_join_, 0));
     return 0;
 }
 

@@ -107,6 +107,11 @@ private:
     // ---- workspace tensors
     float *scratch_ = nullptr;            // transient: split-k slabs, column-sum partials, wgrad slabs
     size_t scratch_floats_ = 0;
+    float* scratch2_ = nullptr;           // scratch of the dVAE branch when it runs on the side stream
+    hipStream_t side_ = nullptr;          // dVAE forward / backward overlap the encoder + decoder work (independent branches)
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    int fork_side(hipStream_t st);
+    int join_side(hipStream_t st);
     float *obs8_, *patches_, *de_[7], *zraw_, *z_, *zdec_;      // zdec_: what the dVAE decoder consumes (z_ or its straight-through form)
     int* tokens_;
     float *dd0_, *dd1_, *dd2_, *dd3_, *dd4_, *ps1_, *dd6_, *dd7_, *dd8_, *dd9_, *ps2_, *recon_, *drecon_;

@@ -289,3 +289,26 @@ def test_autoregressive_generation_matches_oracle():
     em = abs(eng.metrics.cpu()[4].item() - mse.item()) / mse.item()
     log(f"[gen_imgs] recon {e:.2e} mse {em:.2e}")
     assert e < 1e-4 and em < 1e-5
+
+
+def test_side_stream_overlap_matches_single_stream(monkeypatch):
+    """OCRL_OVERLAP=1 runs the dVAE branch on a side stream (fork/join with events): same losses and gradients"""
+    cfg = O.default_cfg(**MID)
+    B = 3
+    P = O.formula_params(cfg)
+    g = torch.Generator().manual_seed(3)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=g).cuda()
+    noise = dev_noise(cfg, O.make_noise(cfg, B, 9))
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("OCRL_OVERLAP", flag)
+        eng = make_engine(cfg, B)
+        load_params(eng, P)
+        for _ in range(2):          # twice: buffers reused across steps under overlap
+            eng.forward(obs, 0.9, train=True, seed=5, noise=noise)
+            eng.backward()
+        torch.cuda.synchronize()
+        outs.append((eng.metrics.cpu().clone(), eng.flat_g.cpu().clone()))
+    assert torch.allclose(outs[0][0][:3], outs[1][0][:3], rtol=1e-6)
+    gmax = outs[0][1].abs().max()
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 1e-5 * gmax
