@@ -156,6 +156,16 @@ int ocrl_iodine_grad_norm(ocrl_iodine* h, void* stream);
 float* ocrl_iodine_metrics(const ocrl_iodine* h);
 int ocrl_iodine_tensor(const ocrl_iodine* h, const char* name, float** ptr, long long* count);
 
+/* ---- data-parallel exchange: one in-place SUM all-reduce of a flat fp32 gradient buffer per step over RCCL
+ * (xGMI); pass gscale = 1/world to ocrl_*_clip_adam for the mean.  For hosts without torch.distributed; librccl is opened
+ * lazily (dlopen).  unique id: 128 bytes produced on rank 0 and broadcast by the host's own means (as ncclGetUniqueId). */
+typedef struct ocrl_comm ocrl_comm;
+int ocrl_comm_unique_id(void* out128, size_t cap);
+int ocrl_comm_init(ocrl_comm** out, int rank, int world, const void* unique_id128);   /* current HIP device = this rank's GPU */
+int ocrl_comm_allreduce(ocrl_comm* c, float* device_buf, long long n, void* stream);
+int ocrl_comm_world(const ocrl_comm* c);
+void ocrl_comm_destroy(ocrl_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

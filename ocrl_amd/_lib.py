@@ -84,6 +84,12 @@ def lib():
     L.ocrl_iodine_metrics.argtypes = [p]
     L.ocrl_iodine_metrics.restype = p
     L.ocrl_iodine_tensor.argtypes = [p, c_char_p, POINTER(p), POINTER(c_longlong)]
+    L.ocrl_comm_unique_id.argtypes = [p, c_size_t]
+    L.ocrl_comm_init.argtypes = [POINTER(p), c_int, c_int, p]
+    L.ocrl_comm_allreduce.argtypes = [p, p, c_longlong, p]
+    L.ocrl_comm_world.argtypes = [p]
+    L.ocrl_comm_destroy.argtypes = [p]
+    L.ocrl_comm_destroy.restype = None
     if L.ocrl_abi_version() != 3:
         raise RuntimeError("libocrl_hip.so ABI version mismatch")
     _lib = L

@@ -72,3 +72,22 @@ def test_train_ocr_runs_iodine(tmp_path):
     assert tr[-1]["train/loss"] < tr[0]["train/loss"]
     ck = torch.load(os.path.join(run, "checkpoints", "model_latest.pth"), weights_only=True)
     assert "refine.lstm.weight_ih" in ck["ocr_module_state_dict"] and ck["step"] == 8
+
+
+def test_cabi_rccl_allreduce_single_rank():
+    """ocrl_comm_* (lazy librccl): world = 1 all-reduce leaves the buffer unchanged; N > 1 needs one GPU per rank (driver's scaling run)"""
+    import ctypes
+    from ocrl_amd import _lib
+    L = _lib.lib()
+    uid = ctypes.create_string_buffer(128)
+    torch.cuda.set_device(0)
+    _lib.check(L.ocrl_comm_unique_id(uid, 128))
+    h = ctypes.c_void_p()
+    _lib.check(L.ocrl_comm_init(ctypes.byref(h), 0, 1, uid))
+    assert L.ocrl_comm_world(h) == 1
+    x = torch.arange(1024, dtype=torch.float32, device="cuda")
+    ref = x.clone()
+    _lib.check(L.ocrl_comm_allreduce(h, _lib.ptr(x), x.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    L.ocrl_comm_destroy(h)
