@@ -504,67 +504,6 @@ __global__ void dropout_mask_kernel(float* __restrict__ y, long long n, float p,
     y[i] = rng_keep(bits, (int)(i & 3), drop_thresh(p)) ? 1.f : 0.f;
 }
 
-// ------------------------------------------------------------------ causal softmax on materialised scores
-// S [BH,T,T] (scores, already scaled) -> P (softmax with -inf above the diagonal) written in place,
-// Pd = dropout(P) written to Pd (may alias S when p == 0).  One workgroup per row.
-__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(float* __restrict__ S, float* __restrict__ Pd, int T, float p,
-                                                                 unsigned long long seed, unsigned site) {
-    __shared__ float red[4];
-    const long long row = blockIdx.x;          // bh*T + q
-    const int q = row % T;
-    float* r = S + row * T;
-    float mx = -INFINITY;
-    for (int k = threadIdx.x; k <= q; k += 256) mx = fmaxf(mx, r[k]);
-    mx = block_max(mx, red);
-    float s = 0.f;
-    for (int k = threadIdx.x; k <= q; k += 256) s += __expf(r[k] - mx);
-    s = block_sum(s, red);
-    const float inv = 1.0f / s;
-    const uint32_t thr = drop_thresh(p);
-    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
-    for (int k = threadIdx.x; k < T; k += 256) {
-        const float pr = k <= q ? __expf(r[k] - mx) * inv : 0.f;
-        float pd = pr;
-        if (p > 0.f) {
-            const uint64_t idx = (uint64_t)row * T + k;
-            pd = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? pr * sc : 0.f;
-        }
-        r[k] = pr;
-        Pd[row * T + k] = pd;
-    }
-}
-// dPd (in place -> dS):  dP = keep/(1-p) * dPd ; dS = P * (dP - sum_k P*dP)
-__global__ __launch_bounds__(256) void softmax_causal_bwd_kernel(const float* __restrict__ P, float* __restrict__ dPd, int T, float p,
-                                                                 unsigned long long seed, unsigned site) {
-    __shared__ float red[4];
-    const long long row = blockIdx.x;
-    const int q = row % T;
-    const uint32_t thr = drop_thresh(p);
-    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
-    float s = 0.f;
-    for (int k = threadIdx.x; k <= q; k += 256) {
-        float dp = dPd[row * T + k];
-        if (p > 0.f) {
-            const uint64_t idx = (uint64_t)row * T + k;
-            dp = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? dp * sc : 0.f;
-        }
-        s += P[row * T + k] * dp;
-    }
-    s = block_sum(s, red);
-    for (int k = threadIdx.x; k < T; k += 256) {
-        float v = 0.f;
-        if (k <= q) {
-            float dp = dPd[row * T + k];
-            if (p > 0.f) {
-                const uint64_t idx = (uint64_t)row * T + k;
-                dp = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? dp * sc : 0.f;
-            }
-            v = P[row * T + k] * (dp - s);
-        }
-        dPd[row * T + k] = v;
-    }
-}
-
 // ------------------------------------------------------------------ cross attention to K (<= 16) slots
 // Q [B,T,d] (projected, unscaled), Km/Vm [B,K,d], heads h, dh = d/h (<= 64).  One thread per (b,head,q).
 // P [B,h,T,K] = softmax (pre-dropout) is saved for the backward.
@@ -1011,16 +950,6 @@ int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigne
 int dropout_mask_launch(float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st) {
     hipLaunchKernelGGL(dropout_mask_kernel, GRID1D(n), 0, st, y, n, p, seed, site);
     OCRL_CHECK_LAUNCH("dropout_mask");
-    return 0;
-}
-int softmax_causal_fwd_launch(float* S, float* Pd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_causal_fwd_kernel, dim3((unsigned)(BH * T)), dim3(256), 0, st, S, Pd, T, p, seed, site);
-    OCRL_CHECK_LAUNCH("softmax_causal_fwd");
-    return 0;
-}
-int softmax_causal_bwd_launch(const float* P, float* dPd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_causal_bwd_kernel, dim3((unsigned)(BH * T)), dim3(256), 0, st, P, dPd, T, p, seed, site);
-    OCRL_CHECK_LAUNCH("softmax_causal_bwd");
     return 0;
 }
 int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, float* O, float* P, int B, int T, int K, int d, int h, float p,

@@ -86,8 +86,6 @@ int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, con
 int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int d, float p, unsigned long long seed, hipStream_t st);
 int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
 int dropout_mask_launch(float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
-int softmax_causal_fwd_launch(float* S, float* Pd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st);
-int softmax_causal_bwd_launch(const float* P, float* dPd, long long BH, int T, float p, unsigned long long seed, unsigned site, hipStream_t st);
 int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, float* O, float* P, int B, int T, int K, int d, int h, float p,
                           unsigned long long seed, unsigned site, hipStream_t st);
 int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,

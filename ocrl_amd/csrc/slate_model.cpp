@@ -106,6 +106,12 @@ SlateModel::SlateModel(const SlateConfig& c) : cfg(c) {
     layout_workspace(false);
 }
 
+SlateModel::~SlateModel() {
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (side_) (void)hipStreamDestroy(side_);
+}
+
 float* SlateModel::P(const std::string& n) const { return p_ + params_[index_.at(n)].offset; }
 float* SlateModel::G(const std::string& n) const { return g_ + params_[index_.at(n)].offset; }
 

@@ -43,6 +43,9 @@ struct Drop { float p = 0.f; unsigned site = 0; };
 class SlateModel {
 public:
     explicit SlateModel(const SlateConfig& c);
+    ~SlateModel();
+    SlateModel(const SlateModel&) = delete;
+    SlateModel& operator=(const SlateModel&) = delete;
     const std::vector<ParamInfo>& params() const { return params_; }
     long long flat_size() const { return flat_size_; }
     long long group_begin(int g) const { return group_begin_[g]; }   // group g = [begin(g), begin(g+1))
