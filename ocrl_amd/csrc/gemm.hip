@@ -15,7 +15,10 @@
 #include "kernels.h"
 #include <stdlib.h>
 
-#define BK 32
+#ifndef OCRL_GEMM_BK
+#define OCRL_GEMM_BK 32      // k extent of a staged tile (development: -DOCRL_GEMM_BK=64 halves the barriers per k at twice the LDS)
+#endif
+#define BK OCRL_GEMM_BK
 
 template <int BM, bool KC>
 struct TileA {
@@ -24,7 +27,8 @@ struct TileA {
     static constexpr int ELEMS = KC ? BM * (BK + 4) : BK * (BM + 4);
     // float4 per thread per k-tile.  !KC: a k-row is BM/4 float4, 256/(BM/4) k-rows per pass (BM = 192: 5 rows, threads >= 240 idle)
     static constexpr int F4 = BM / 4, RPP = 256 / F4;
-    static constexpr int NV = KC ? BM / 32 : (BK + RPP - 1) / RPP;
+    static constexpr int KF4 = BK / 4, KRPP = 256 / KF4;       // KC: float4 per row, rows per pass
+    static constexpr int NV = KC ? BM / KRPP : (BK + RPP - 1) / RPP;
 };
 
 // global -> registers for one operand tile.  rows = extent along m (or n), base points at
@@ -51,10 +55,11 @@ __device__ inline void load_tile(const float* __restrict__ g, int ld, int rows_v
                                  float4 (&r)[TileA<BMN, KC>::NV], const ADrop& dr, int mn0, int k0) {
     const int t = threadIdx.x;
     if (KC) {
-        const int c4 = t & 7, r0 = t >> 3;
+        constexpr int KF4 = TileA<BMN, KC>::KF4, KRPP = TileA<BMN, KC>::KRPP;
+        const int c4 = t % KF4, r0 = t / KF4;
 #pragma unroll
-        for (int i = 0; i < BMN / 32; ++i) {
-            const int row = r0 + 32 * i;
+        for (int i = 0; i < TileA<BMN, KC>::NV; ++i) {
+            const int row = r0 + KRPP * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < rows_valid && c4 * 4 < k_valid) {
                 v = *reinterpret_cast<const float4*>(g + (size_t)row * ld + c4 * 4);
@@ -84,9 +89,10 @@ __device__ inline void store_tile(float* __restrict__ s, const float4 (&r)[TileA
     const int t = threadIdx.x;
     constexpr int LD = TileA<BMN, KC>::LD;
     if (KC) {
-        const int c4 = t & 7, r0 = t >> 3;
+        constexpr int KF4 = TileA<BMN, KC>::KF4, KRPP = TileA<BMN, KC>::KRPP;
+        const int c4 = t % KF4, r0 = t / KF4;
 #pragma unroll
-        for (int i = 0; i < BMN / 32; ++i) *reinterpret_cast<float4*>(s + (r0 + 32 * i) * LD + c4 * 4) = r[i];
+        for (int i = 0; i < TileA<BMN, KC>::NV; ++i) *reinterpret_cast<float4*>(s + (r0 + KRPP * i) * LD + c4 * 4) = r[i];
     } else {
         constexpr int F4 = BMN / 4;
         constexpr int RPP = 256 / F4;
