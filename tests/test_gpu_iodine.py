@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 TINY = dict(obs_size=16, num_slots=3, num_iterations=3)
 S32 = dict(obs_size=32, num_slots=7, num_iterations=5)          # BASELINE config 4's slot / iteration counts
 NOLN = dict(obs_size=16, num_slots=4, num_iterations=2, layer_norm=False)
+FULL = dict(obs_size=64, num_slots=7, num_iterations=5)          # BASELINE config 4 at full resolution (B = 1 keeps the CPU oracle to seconds)
 
 
 def dims(cfg):
@@ -26,7 +27,7 @@ def make_engine(cfg, B):
     return IodineEngine(dims(cfg), max_batch=B)
 
 
-@pytest.mark.parametrize("tag,over,B", [("io_tiny", TINY, 2), ("io_s32", S32, 2), ("io_noln", NOLN, 3)])
+@pytest.mark.parametrize("tag,over,B", [("io_tiny", TINY, 2), ("io_s32", S32, 2), ("io_noln", NOLN, 3), ("io_full", FULL, 1)])
 def test_iodine_forward_backward(tag, over, B):
     cfg = IO.default_cfg(**over)
     P = IO.formula_params(cfg)
