@@ -17,6 +17,7 @@ LONG = dict(obs_size=64, vocab_size=256, num_slots=4, num_iterations=1, num_dec_
 K16 = dict(obs_size=16, vocab_size=256, num_slots=16, num_iterations=2, num_dec_blocks=1)     # BASELINE config 5's slot count (two slot blocks)
 K11 = dict(obs_size=16, vocab_size=256, num_slots=11, num_iterations=2, num_dec_blocks=1)     # uneven slot blocks (6 + 5)
 RAGGED = dict(obs_size=24, vocab_size=256, num_slots=3, num_iterations=2, num_dec_blocks=1)   # 24x24: partial conv tiles, T = 36 < one attention tile, N = 576
+V4096 = dict(obs_size=16, vocab_size=4096, num_slots=4, num_iterations=2, num_dec_blocks=1)   # real vocabulary: the 16-values-per-thread vocabulary kernels
 HARD = dict(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, hard=True)   # straight-through dVAE sample
 
 
@@ -82,7 +83,7 @@ def compare_grads(tag, eng, trainer):
     return worst, rows
 
 
-@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2), ("hard", HARD, 2), ("ragged", RAGGED, 3)])
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2), ("hard", HARD, 2), ("ragged", RAGGED, 3), ("v4096", V4096, 2)])
 def test_forward_backward_eval(tag, over, B):
     """dropout off: every stage of the forward, then every parameter gradient"""
     cfg = O.default_cfg(**over)
