@@ -313,3 +313,37 @@ def test_side_stream_overlap_matches_single_stream(monkeypatch):
     assert torch.allclose(outs[0][0][:3], outs[1][0][:3], rtol=1e-6)
     gmax = outs[0][1].abs().max()
     assert (outs[0][1] - outs[1][1]).abs().max() <= 1e-5 * gmax
+
+
+def test_full_size_batch_additivity():
+    """BASELINE config A shapes (128x128, 6 slots, 3 iterations, vocab 4096, 4 decoder blocks) are beyond the CPU oracle's reach in
+    a test; the domain's size-independent property is additivity over images: every loss is sum/B and no operator mixes images, so
+    B * (loss, gradient) of a batch equals the sum over its halves (same weights, same per-image noise, dropout off)."""
+    cfg = O.default_cfg(obs_size=128, num_slots=6, num_iterations=3)
+    B = 4
+    P = O.formula_params(cfg)
+    g = torch.Generator().manual_seed(42)
+    obs = torch.rand(B, 3, 128, 128, generator=g).cuda()
+    T, V, K, D = 1024, cfg.vocab_size, cfg.num_slots, cfg.slot_size
+    gg = torch.Generator(device="cuda").manual_seed(7)
+    noise = dict(z=torch.empty(B, T, V, device="cuda").exponential_(generator=gg), z_hard=torch.empty(B, T, V, device="cuda").exponential_(generator=gg),
+                 slots=torch.randn(B, K, D, device="cuda", generator=gg))
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+
+    def run(sl):
+        n = {k: v[sl].contiguous() for k, v in noise.items()}
+        m = eng.forward(obs[sl].contiguous(), 0.7, train=False, seed=1, noise=n)
+        eng.backward()
+        torch.cuda.synchronize()
+        nb = obs[sl].shape[0]
+        return m[:3].cpu().double() * nb, eng.flat_g.cpu().double() * nb
+
+    l_all, g_all = run(slice(0, B))
+    l_a, g_a = run(slice(0, B // 2))
+    l_b, g_b = run(slice(B // 2, B))
+    assert torch.isfinite(l_all).all() and torch.isfinite(g_all).all()
+    err_l = ((l_a + l_b - l_all).abs() / l_all.abs().clamp_min(1e-12)).max().item()
+    err_g = ((g_a + g_b - g_all).abs().max() / g_all.abs().max()).item()
+    log(f"[full-size additivity] loss terms {err_l:.2e}, gradients {err_g:.2e} (|g|max {g_all.abs().max().item():.3e})")
+    assert err_l < 1e-5 and err_g < 1e-4
