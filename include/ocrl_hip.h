@@ -124,6 +124,19 @@ int ocrl_attention_bwd(const float* q, const float* k, const float* v, const flo
 int ocrl_prof_enable(unsigned tag_mask);
 int ocrl_prof_collect(double* ms, long long* count, int ntags);
 
+/* ---- the slot-attention loop on its own (SlotAttention.forward, ocrs/common/slot_attn.py:47-102; single head) ----
+ * x [B,N,64] inputs (before norm_inputs), slots0 [B,K,D]; `w` = 17 device pointers in the reference's parameter order:
+ * norm_inputs.{weight,bias}, norm_slots.{weight,bias}, norm_mlp.{weight,bias}, project_q / project_k / project_v .weight,
+ * gru.weight_ih, gru.weight_hh, gru.bias_ih, gru.bias_hh, mlp.0.{weight,bias}, mlp.2.{weight,bias}.
+ * Outputs: slots [B,K,D], attn [B,N,K] (last iteration, before the epsilon; may be NULL).  The workspace keeps the saved
+ * activations: call _bwd with the same ws right after _fwd.  _bwd: dslots [B,K,D] -> dx [B,N,64], dslots0 [B,K,D] and the
+ * 17 weight gradients `dw` (same order and shapes).  Slot / MLP widths: multiples of 64 up to 256; 1 <= K <= 16. */
+size_t ocrl_slot_attention_ws_floats(int B, int K, int D, int H, int I);
+int ocrl_slot_attention_fwd(const float* x, const float* slots0, const float* const* w, float* slots, float* attn, int B, int N, int K, int D,
+                            int H, int I, float* ws, size_t ws_floats, void* stream);
+int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H,
+                            int I, float* ws, size_t ws_floats, void* stream);
+
 /* ---- IODINE (ocrs/iodine/iodine_module.py:14-271, ocrs/iodine/iodine.py:4-14, ocrs/base.py:60-74): SURVEY.md §8 row a20 ----
  * Same conventions as the SLATE handle: flat fp32 parameter / gradient / Adam buffers in the reference's
  * _module.parameters() order and state_dict names, adopted from the caller; one workspace; all work on the caller's stream. */

@@ -84,6 +84,10 @@ def lib():
     L.ocrl_iodine_metrics.argtypes = [p]
     L.ocrl_iodine_metrics.restype = p
     L.ocrl_iodine_tensor.argtypes = [p, c_char_p, POINTER(p), POINTER(c_longlong)]
+    L.ocrl_slot_attention_ws_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
+    L.ocrl_slot_attention_ws_floats.restype = c_size_t
+    L.ocrl_slot_attention_fwd.argtypes = [p, p, POINTER(p), p, p, c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
+    L.ocrl_slot_attention_bwd.argtypes = [p, p, p, p, POINTER(p), c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
     L.ocrl_comm_unique_id.argtypes = [p, c_size_t]
     L.ocrl_comm_init.argtypes = [POINTER(p), c_int, c_int, p]
     L.ocrl_comm_allreduce.argtypes = [p, p, c_longlong, p]
