@@ -48,61 +48,37 @@ __device__ inline float redg_sum(float v) {           // over the 4 lanes of one
     return v;
 }
 
-// out[j][col] = scale * sum_e in[j][e] * Wt[e*ldw + col] + bias[col],  col < NC, j < K   (in/out in LDS; E % 4 == 0, rows 16-byte aligned).
-// Thread = (E-slice g, column): the reduction over e is split over blockDim/NC thread groups (contiguous slices) and combined
-// through `scr` ([G][K][NC] floats) in a fixed order.  Per 4 values of e a thread issues 4 weight loads (L2) and K broadcast
-// ds_read_b128 of the inputs — one LDS instruction per 4 FMAs instead of one per FMA.  Ends with a workgroup barrier.
+// out[j][col] = scale * sum_e in[j][e] * Wn[col*ldw + e] + bias[col],  col < NC, j < K   (in/out in LDS; E, NC multiples of 16).
+// The K <= 16 slot rows are the M side of v_mfma_f32_16x16x4_f32 (rows >= K fed as zeros), a wave owns 16-column tiles of the
+// output; per 16 values of e a lane issues one float4 weight load (the k-contiguous orientation of the weight, L2 resident) and
+// one ds_read_b128 of its slot row and feeds 4 MFMAs — the slot-side products take microseconds instead of walking e serially.
+// Ends with a workgroup barrier.
 template <int K>
-__device__ __forceinline__ void matvec(const float* __restrict__ Wt, int ldw, int E, int NC, const float* in, int ldin, float* out, int ldout,
-                                       const float* __restrict__ bias, float scale, float* scr) {
-    const int nt = blockDim.x, tid = threadIdx.x;
-    const int ncp = (NC + 63) & ~63;
-    int G = nt / ncp;
-    if (G > 16) G = 16;
-    if (G < 1) G = 1;
-    const int EB = (((E + G - 1) / G) + 3) & ~3;          // slice length, multiple of 4
-    const int ncols = G > 1 ? 1 : (NC + nt - 1) / nt;     // G == 1: a thread may own several columns
-    for (int cc = 0; cc < ncols; ++cc) {
-        const int g = G > 1 ? tid / ncp : 0;
-        const int col = G > 1 ? tid - g * ncp : tid + cc * nt;
-        const bool act = g < G && col < NC;
-        float acc[K];
-#pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] = 0.f;
-        if (act) {
-            const int e0 = g * EB, e1 = (e0 + EB < E) ? e0 + EB : E;
-            const float* wp = Wt + (size_t)e0 * ldw + col;
-#pragma unroll 2
-            for (int e = e0; e < e1; e += 4, wp += 4 * (size_t)ldw) {
-                const float w0 = wp[0], w1 = wp[ldw], w2 = wp[2 * (size_t)ldw], w3 = wp[3 * (size_t)ldw];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(in + j * ldin + e);
-                    acc[j] += v.x * w0 + v.y * w1 + v.z * w2 + v.w * w3;
-                }
-            }
+__device__ __forceinline__ void matvec(const float* __restrict__ Wn, int ldw, int E, int NC, const float* in, int ldin, float* out, int ldout,
+                                       const float* __restrict__ bias, float scale) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
+    const int ntile = NC >> 4, nks = E >> 4;
+    const float* arow = in + (li < K ? li : 0) * ldin + 4 * g;
+    for (int tile = wv; tile < ntile; tile += nw) {
+        const int col = tile * 16 + li;
+        const float* wrow = Wn + (size_t)col * ldw + 4 * g;
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s = 0; s < nks; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s);
+            float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
+            if (li >= K) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = MFMA16(a.x, b.x, acc);
+            acc = MFMA16(a.y, b.y, acc);
+            acc = MFMA16(a.z, b.z, acc);
+            acc = MFMA16(a.w, b.w, acc);
         }
-        if (G > 1) {
-            if (act) {
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-                for (int j = 0; j < K; ++j) scr[(g * K + j) * NC + col] = acc[j];
-            }
-        } else if (act) {
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int j = 0; j < K; ++j) out[j * ldout + col] = acc[j] * scale + bv;
-        }
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < K) out[(4 * g + r) * ldout + col] = acc[r] * scale + bv;      // acc[r] = row (slot) 4g + r, column li
     }
     __syncthreads();
-    if (G > 1) {
-        for (int i = tid; i < K * NC; i += nt) {
-            const int j = i / NC, c = i - j * NC;
-            float s = 0.f;
-            for (int w = 0; w < G; ++w) s += scr[(w * K + j) * NC + c];
-            out[j * ldout + c] = s * scale + (bias ? bias[c] : 0.f);
-        }
-        __syncthreads();
-    }
 }
 
 // LayerNorm of K rows of width D held in LDS (one wave per row).
@@ -297,8 +273,8 @@ __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, Sa
             if (sv) rows_to_global(sB, sv + so.sprev, so.ld, kv, D);
             ln_rows(sB, sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
             __syncthreads();
-            matvec<KB>(W + wo.WqT, D, D, D, sn, D, q, D, nullptr, 1.f, tiles);
-            matvec<KB>(W + wo.Wk, C, D, C, q, D, qp + j0 * C, C, nullptr, p.scale, tiles);
+            matvec<KB>(W + wo.Wq, D, D, D, sn, D, q, D, nullptr, 1.f);
+            matvec<KB>(W + wo.WkT, D, D, C, q, D, qp + j0 * C, C, nullptr, p.scale);
             if (sv) {
                 rows_to_global(sn, sv + so.sn, so.ld, kv, D);
                 rows_to_global(q, sv + so.q, so.ld, kv, D);
@@ -334,9 +310,9 @@ __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, Sa
             const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
             float* sB = s + j0 * D;
             float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
-            matvec<KB>(W + wo.WvT, D, C, D, up + j0 * C, C, u, D, nullptr, 1.f, tiles);
-            matvec<KB>(W + wo.WihT, 3 * D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f, tiles);
-            matvec<KB>(W + wo.WhhT, 3 * D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f, tiles);
+            matvec<KB>(W + wo.Wv, C, C, D, up + j0 * C, C, u, D, nullptr, 1.f);
+            matvec<KB>(W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f);
+            matvec<KB>(W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f);
             for (int i = tid; i < KB * D; i += nt) {
                 const int j = i / D, c = i - j * D;
                 const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
@@ -353,10 +329,10 @@ __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, Sa
             __syncthreads();
             ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, KB, D);      // sn = m
             __syncthreads();
-            matvec<KB>(W + wo.W0T, H, D, H, sn, D, hid, H, W + wo.b0, 1.f, tiles);
+            matvec<KB>(W + wo.W0, D, D, H, sn, D, hid, H, W + wo.b0, 1.f);
             for (int i = tid; i < KB * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
             __syncthreads();
-            matvec<KB>(W + wo.W2T, D, H, D, hid, H, u, D, W + wo.b2, 1.f, tiles);      // u = mlp out
+            matvec<KB>(W + wo.W2, H, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
             for (int i = tid; i < kv * D; i += nt) sB[i] = q[i] + u[i];
             if (sv) {
                 rows_to_global(sn, sv + so.m, so.ld, kv, D);
@@ -552,7 +528,7 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
             // ---- residual MLP backward: s_new = sg + W2 relu(W0 m + b0) + b2,  m = LN_m(sg)
             rows_to_global(dsB, gr + go.out, go.ld, kv, D);
             rows_from_global(t0, sv + so.sg, so.ld, kv, D);
-            matvec<KB>(W + wo.W2, H, D, H, dsB, D, dhid, H, nullptr, 1.f, tiles);          // dhid[h] = sum_d ds[d] W2[d][h]
+            matvec<KB>(W + wo.W2T, D, D, H, dsB, D, dhid, H, nullptr, 1.f);          // dhid[h] = sum_d ds[d] W2[d][h]
             for (int i = tid; i < kv * H; i += nt) {
                 const int j = i / H, c = i - j * H;
                 const float v = sv[j * so.ld + so.hid + c] > 0.f ? dhid[i] : 0.f;
@@ -560,7 +536,7 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
                 gr[j * go.ld + go.hid + c] = v;
             }
             __syncthreads();
-            matvec<KB>(W + wo.W0, D, H, D, dhid, H, t1, D, nullptr, 1.f, tiles);           // dm[e] = sum_h dhid[h] W0[h][e]
+            matvec<KB>(W + wo.W0T, H, H, D, dhid, H, t1, D, nullptr, 1.f);           // dm[e] = sum_h dhid[h] W0[h][e]
             ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_m_g, dg_m, db_m, kv, D);                 // ds = d s_gru
             __syncthreads();
             // ---- GRU backward
@@ -579,12 +555,12 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
             __syncthreads();
             rows_to_global(dgi, gr + go.gi, go.ld, kv, 3 * D);
             rows_to_global(dgh, gr + go.gh, go.ld, kv, 3 * D);
-            matvec<KB>(W + wo.Wih, D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f, tiles);   // du[e] = sum_g dgi[g] Wih[g][e]
-            matvec<KB>(W + wo.Whh, D, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f, tiles);   // dh via the recurrent weights
+            matvec<KB>(W + wo.WihT, 3 * D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f);   // du[e] = sum_g dgi[g] Wih[g][e]
+            matvec<KB>(W + wo.WhhT, 3 * D, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f);   // dh via the recurrent weights
             for (int i = tid; i < kv * D; i += nt) t2B[i] += t0[i];
             rows_to_global(t1, gr + go.u, go.ld, kv, D);
             // ---- u = up Wv^T
-            matvec<KB>(W + wo.Wv, C, D, C, t1, D, dup + j0 * C, C, nullptr, 1.f, tiles);   // dup[c] = sum_d du[d] Wv[d][c]
+            matvec<KB>(W + wo.WvT, D, D, C, t1, D, dup + j0 * C, C, nullptr, 1.f);   // dup[c] = sum_d du[d] Wv[d][c]
         }
         rows_from_global(qp, sv0 + so.qp, so.ld, K, C);
         if (tid < K) {
@@ -640,10 +616,10 @@ __global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, Sa
             float* gr = gr0 + (size_t)j0 * go.ld;
             float* dsB = ds + j0 * D;
             // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
-            matvec<KB>(W + wo.WkT, D, C, D, dqp + j0 * C, C, t1, D, nullptr, p.scale, tiles);   // t1 = dq
+            matvec<KB>(W + wo.Wk, C, C, D, dqp + j0 * C, C, t1, D, nullptr, p.scale);   // t1 = dq
             rows_to_global(t1, gr + go.q, go.ld, kv, D);
             rows_from_global(t0, sv + so.sprev, so.ld, kv, D);
-            matvec<KB>(W + wo.Wq, D, D, D, t1, D, dsB, D, nullptr, 1.f, tiles);                 // ds = dsn
+            matvec<KB>(W + wo.WqT, D, D, D, t1, D, dsB, D, nullptr, 1.f);                 // ds = dsn
             for (int i = tid; i < kv * D; i += nt) { t1[i] = dsB[i]; dsB[i] = t2[j0 * D + i]; }
             __syncthreads();
             ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_s_g, dg_s, db_s, kv, D);                      // ds = dh + LN_s backward
