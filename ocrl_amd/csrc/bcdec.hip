@@ -320,10 +320,10 @@ __global__ __launch_bounds__(256) void bc_mix_kernel(const float* __restrict__ o
     float loss = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / hw, r = i % hw;
-        float4 o[8];
+        float4 o[16];
         float mx = -INFINITY;
         for (int k = 0; k < K; ++k) { o[k] = *reinterpret_cast<const float4*>(out4 + ((b * K + k) * hw + r) * 4); mx = fmaxf(mx, o[k].w); }
-        float m[8], se = 0.f;
+        float m[16], se = 0.f;
         for (int k = 0; k < K; ++k) { m[k] = __expf(o[k].w - mx); se += m[k]; }
         float rc[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < K; ++k) { m[k] /= se; rc[0] += o[k].x * m[k]; rc[1] += o[k].y * m[k]; rc[2] += o[k].z * m[k]; }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void bc_mix_kernel(const float* __restrict__ o
         }
         if (recon) *reinterpret_cast<float4*>(recon + i * 4) = make_float4(rc[0], rc[1], rc[2], 0.f);
         if (dout4) {
-            float dm[8], dot = 0.f;
+            float dm[16], dot = 0.f;
             for (int k = 0; k < K; ++k) { dm[k] = dr[0] * o[k].x + dr[1] * o[k].y + dr[2] * o[k].z; dot += m[k] * dm[k]; }
             for (int k = 0; k < K; ++k)
                 *reinterpret_cast<float4*>(dout4 + ((b * K + k) * hw + r) * 4) = make_float4(dr[0] * m[k], dr[1] * m[k], dr[2] * m[k], m[k] * (dm[k] - dot));
@@ -423,7 +423,7 @@ int bc_c4_wgrad_launch(const float* X, const float* dY, float* part, int Bn, int
 }
 int bc_mix_launch(const float* out4, const float* obs, float* recon, float* dout4, float* loss_out, int B, int K, int S, int C, float* ws,
                   size_t ws_floats, hipStream_t st) {
-    OCRL_REQUIRE(K <= 8 && C <= 3 && ws_floats >= 1024, "mixture: K <= 8, C <= 3");
+    OCRL_REQUIRE(K <= 16 && C <= 3 && ws_floats >= 1024, "mixture: K <= 16, C <= 3");
     hipLaunchKernelGGL(bc_mix_kernel, dim3(1024), dim3(256), 0, st, out4, obs, recon, dout4, ws, B, K, S, C, 1.0f / B);
     OCRL_CHECK_LAUNCH("bc_mix");
     return reduce_partials_launch(ws, 1024, loss_out, 1.0f / B, 0, st);

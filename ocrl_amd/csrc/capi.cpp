@@ -47,7 +47,7 @@ int ocrl_slate_create(const ocrl_slate_config* c, ocrl_slate** out) {
     k.mlp_hidden = c->mlp_hidden; k.num_blocks = c->num_dec_blocks; k.num_heads = c->num_dec_heads; k.dropout = c->dropout;
     k.max_batch = c->max_batch;
     k.hard = c->hard ? 1 : 0; k.use_bcdec = c->use_bcdec ? 1 : 0;
-    if (k.use_bcdec && (c->num_slots > 8 || c->obs_size < 5)) { ocrl_set_error("ocrl_slate_create: broadcast decoder needs num_slots <= 8 and obs_size >= 5"); return 1; }
+    if (k.use_bcdec && (c->num_slots > 16 || c->obs_size < 5)) { ocrl_set_error("ocrl_slate_create: broadcast decoder needs num_slots <= 16 and obs_size >= 5"); return 1; }
     ocrl_slate* h = new (std::nothrow) ocrl_slate;
     if (!h) { ocrl_set_error("out of memory"); return 1; }
     h->m = new (std::nothrow) SlateModel(k);

@@ -209,9 +209,10 @@ def test_device_rng_statistics():
 
 BC = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=1, use_bcdec=True)
 BC32 = dict(obs_size=32, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, use_bcdec=True)
+BC12 = dict(obs_size=16, vocab_size=256, num_slots=12, num_iterations=2, num_dec_blocks=1, use_bcdec=True)      # more than 8 slots
 
 
-@pytest.mark.parametrize("tag,over,B", [("bcdec16", BC, 2), ("bcdec32", BC32, 3)])
+@pytest.mark.parametrize("tag,over,B", [("bcdec16", BC, 2), ("bcdec32", BC32, 3), ("bcdec_k12", BC12, 2)])
 def test_broadcast_decoder_config_matches_oracle(tag, over, B):
     """Slot-Attention configuration (use_bcdec): loss, reconstruction, every gradient, then two update() steps"""
     cfg = O.default_cfg(**over)
