@@ -697,6 +697,31 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------ first conv layer's weight gradient as a GEMM
+// col[(b,y,x)][tap*C + c] = x8[b][y+ky-2][x+kx-2][c] (0 outside; columns >= 25*C are zero); x8 is NHWC with 8-float pixels
+__global__ void im2col5_kernel(const float* __restrict__ x8, float* __restrict__ col, long long npix, int H, int W, int C, int ldc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * ldc) return;
+    const int j = i % ldc;
+    const long long pix = i / ldc;
+    float v = 0.f;
+    if (j < 25 * C) {
+        const int c = j % C, tap = j / C;
+        const int x = pix % W, y = (pix / W) % H;
+        const long long b = pix / ((long long)W * H);
+        const int yy = y + tap / 5 - 2, xx = x + tap % 5 - 2;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = x8[((b * H + yy) * W + xx) * 8 + c];
+    }
+    col[i] = v;
+}
+// dW[co][c][tap] = dWp[co][tap*C + c]
+__global__ void unpack5_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int C, int ldc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 64 * 25 * C) return;
+    const int tap = i % 25, c = (i / 25) % C, co = i / (25 * C);
+    dW[i] = dWp[co * ldc + tap * C + c];
+}
+
 // ------------------------------------------------------------------ misc
 __global__ void fill_kernel(float* __restrict__ x, long long n, float v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1031,5 +1056,16 @@ int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t
 int onehot_launch(const int* tokens, float* z, long long rows, int V, hipStream_t st) {
     hipLaunchKernelGGL(onehot_kernel, GRID1D(rows * V), 0, st, tokens, z, rows * V, V);
     OCRL_CHECK_LAUNCH("onehot");
+    return 0;
+}
+
+int im2col5_launch(const float* x8, float* col, long long npix, int H, int W, int C, int ldc, hipStream_t st) {
+    hipLaunchKernelGGL(im2col5_kernel, GRID1D(npix * ldc), 0, st, x8, col, npix, H, W, C, ldc);
+    OCRL_CHECK_LAUNCH("im2col5");
+    return 0;
+}
+int unpack5_launch(const float* dWp, float* dW, int C, int ldc, hipStream_t st) {
+    hipLaunchKernelGGL(unpack5_kernel, GRID1D(64 * 25 * C), 0, st, dWp, dW, C, ldc);
+    OCRL_CHECK_LAUNCH("unpack5");
     return 0;
 }

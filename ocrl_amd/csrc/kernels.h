@@ -94,6 +94,8 @@ int fill_launch(float* x, long long n, float v, hipStream_t st);
 int axpy_launch(const float* x, float* y, long long n, float a, hipStream_t st);
 int posmap_launch(const float* Wpos, const float* bpos, float* out, int S, int C, hipStream_t st);
 int posgrid_launch(float* out, int S, hipStream_t st);
+int im2col5_launch(const float* x8, float* col, long long npix, int H, int W, int C, int ldc, hipStream_t st);
+int unpack5_launch(const float* dWp, float* dW, int C, int ldc, hipStream_t st);
 int pad_cols_launch(const float* in, int ldi, float* out, int ldo, long long R, int C, int Cout, hipStream_t st);
 
 // ------------------------------------------------------------------ slot_attn.hip

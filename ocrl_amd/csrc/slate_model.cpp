@@ -209,6 +209,10 @@ void SlateModel::layout_workspace(bool commit) {
     gmem_ = carve(nullptr, BK * d); gck_ = carve(nullptr, BK * d); gcv_ = carve(nullptr, BK * d);
     gdA_ = carve(nullptr, BN * 64); gdB_ = carve(nullptr, BN * 64);
     }
+    {
+        const int ldc0 = (25 * cfg.obs_channels + 3) & ~3;
+        col0_ = carve(nullptr, BN * ldc0); dw0p_ = carve(nullptr, (size_t)64 * ldc0);
+    }
     if (!commit) ws_bytes_ = ws_off_ + 4096;
 }
 
@@ -650,7 +654,14 @@ int SlateModel::bwd_encoder(hipStream_t st) {
     RC(conv_layer_fwd(gA_, cw_bwd_[2], nullptr, gB_, B, S, S, 5, 64, 0, nullptr, e2_, st));
     RC(conv_layer_wgrad(e1_, gB_, G("_enc._encoder.1.m.weight"), G("_enc._encoder.1.m.bias"), B, S, S, 5, 64, 64, st));
     RC(conv_layer_fwd(gB_, cw_bwd_[1], nullptr, gA_, B, S, S, 5, 64, 0, nullptr, e1_, st));
-    RC(conv_layer_wgrad(obs8_, gA_, G("_enc._encoder.0.m.weight"), G("_enc._encoder.0.m.bias"), B, S, S, 5, 8, cfg.obs_channels, st));
+    // first layer (3 input channels): on the conv wgrad kernel its 8-of-64 useful MFMA columns cost 1.5 ms; as
+    // dW = dY^T im2col(obs) it is one [64 x 75] split-K product over the B*N pixels
+    {
+        const int ch = cfg.obs_channels, ldc0 = (25 * ch + 3) & ~3;
+        RC(im2col5_launch(obs8_, col0_, BN, S, S, ch, ldc0, st));
+        RC(lin_bwd_w(gA_, 64, col0_, ldc0, dw0p_, G("_enc._encoder.0.m.bias"), BN, 64, ldc0, 1.f, st));
+        RC(unpack5_launch(dw0p_, G("_enc._encoder.0.m.weight"), ch, ldc0, st));
+    }
     return 0;
 }
 

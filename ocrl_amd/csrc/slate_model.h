@@ -140,6 +140,7 @@ private:
     float *gA_, *gB_;                     // [B*N,64] (CNN encoder / slot-attention input gradients)
     float *gdA_, *gdB_;                   // dVAE decoder gradient ping-pong (up to [B*4T,256])
     float *gmap_;
+    float *col0_, *dw0p_;                 // first conv layer: im2col of the observation and the [64, 25*ch (+pad)] gradient product
     // broadcast decoder (use_bcdec)
     float *bc_Wc_, *bc_W1r_, *bc_P1_, *bc_M_, *bc_T_, *bc_c1_, *bc_c2_, *bc_c3_, *bc_out4_, *bc_dout4_, *bc_gA_, *bc_gB_;
     float *bc_pk_[2], *bc_pkb_[2], *bc_Wk4_, *bc_Wb4_, *bc_dW1r_, *bc_dWc_, *bc_dT_, *bc_dM_, *bc_G1_;
