@@ -119,7 +119,7 @@ __device__ inline void load_frag(const float* __restrict__ s, int row0, int c, f
 }
 
 template <int BM, int BN, bool AKC, bool BKC, bool SB, bool ADROP>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 * 64) ? 4 : 1)) void gemm_kernel(GemmArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int AE = TileA<BM, AKC>::ELEMS, BE = TileA<BN, BKC>::ELEMS;
@@ -261,6 +261,61 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const float* Mk = p.mask ? p.mask + (size_t)batch * p.sMask : nullptr;
     const uint32_t thr = drop_thresh(p.drop_p);
     const float dscale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    // Fast path: every 32x32 accumulator tile goes through a wave-private LDS patch and leaves as float4 rows — 4x fewer store
+    // (and mask / residual load) instructions, full 128-byte lines, and one dropout draw per 4 outputs instead of one per output.
+    const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!R || ((p.ldr & 3) == 0 && (((uintptr_t)R) & 15) == 0)) &&
+                     (!Mk || ((p.ldmask & 3) == 0 && (((uintptr_t)Mk) & 15) == 0)) && (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && p.diag != 1;
+    if (vec) {
+        __syncthreads();                                   // the operand tiles are dead: their LDS becomes four staging patches
+        float* patch = smem + wave * (32 * 36);
+        const int rr0 = lane >> 3, c4 = lane & 7;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[i][j][r] * p.alpha;
+                __builtin_amdgcn_wave_barrier();
+                const int col = n0 + wn0 + j * 32 + c4 * 4;
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rr = ps * 8 + rr0;
+                    const int row = m0 + wm0 + i * 32 + rr;
+                    float4 v = *reinterpret_cast<const float4*>(patch + rr * 36 + c4 * 4);
+                    if (row >= p.M || col >= p.N) continue;
+                    if (!partial) {
+                        if (p.bias) {
+                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        }
+                        if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        else if (p.relu == 2) {
+                            v.x = v.x > 0.f ? v.x : __expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : __expf(v.y) - 1.f;
+                            v.z = v.z > 0.f ? v.z : __expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : __expf(v.w) - 1.f;
+                        }
+                        if (p.drop_p > 0.f) {
+                            const uint64_t idx = ((uint64_t)batch * p.M + row) * (uint64_t)p.N + col;      // multiple of 4
+                            const uint2 bits = rng_bits4(p.drop_seed, p.drop_site, idx >> 2);
+                            v.x = rng_keep(bits, 0, thr) ? v.x * dscale : 0.f; v.y = rng_keep(bits, 1, thr) ? v.y * dscale : 0.f;
+                            v.z = rng_keep(bits, 2, thr) ? v.z * dscale : 0.f; v.w = rng_keep(bits, 3, thr) ? v.w * dscale : 0.f;
+                        }
+                        if (Mk) {
+                            const float4 mk = *reinterpret_cast<const float4*>(Mk + (size_t)row * p.ldmask + col);
+                            const float e = p.mask_elu ? 1.f : 0.f;
+                            v.x = mk.x > 0.f ? v.x : e * v.x * (mk.x + 1.f); v.y = mk.y > 0.f ? v.y : e * v.y * (mk.y + 1.f);
+                            v.z = mk.z > 0.f ? v.z : e * v.z * (mk.z + 1.f); v.w = mk.w > 0.f ? v.w : e * v.w * (mk.w + 1.f);
+                        }
+                        if (R) {
+                            const float4 rv = *reinterpret_cast<const float4*>(R + (size_t)row * p.ldr + col);
+                            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        }
+                    }
+                    *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + col) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
