@@ -137,8 +137,47 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
         }
     }
 
-    // ---- epilogue: bias, relu, + posmap, relu-backward mask
+    // ---- epilogue: bias, relu / elu, + posmap, activation-derivative mask.  The 32-pixel x 64-channel wave tile goes through a
+    // wave-private LDS patch (the halo is dead once every wave has left the tap loop) and leaves as float4 runs of a pixel's
+    // channels: 8 store instructions of full 256-byte pixels instead of 32 two-pixel scalar stores, float4 posmap / mask reads.
     const int y = y0 + wave;
+    if (HH_ * HW_ * LDH >= 4 * 32 * (COUT + 4)) {       // (compile-time) the halo region holds the four patches
+        __syncthreads();
+        float* patch = smem + wave * 32 * (COUT + 4);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * (COUT + 4) + tn * 32 + li] = tn == 0 ? acc0[r] : acc1[r];
+        __builtin_amdgcn_wave_barrier();
+        if (y >= p.H) return;
+        const int c4 = lane & 15, px0 = lane >> 4;
+        const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int px = ps * 4 + px0, x = x0 + px;
+            if (x >= p.W) continue;
+            float4 v = *reinterpret_cast<const float4*>(patch + px * (COUT + 4) + c4 * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (p.relu == 2) {
+                v.x = v.x > 0.f ? v.x : __expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : __expf(v.y) - 1.f;
+                v.z = v.z > 0.f ? v.z : __expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : __expf(v.w) - 1.f;
+            }
+            const size_t pix = ((size_t)b * p.H + y) * p.W + x;
+            if (p.posmap) {
+                const float4 pm = *reinterpret_cast<const float4*>(p.posmap + ((size_t)y * p.W + x) * COUT + c4 * 4);
+                v.x += pm.x; v.y += pm.y; v.z += pm.z; v.w += pm.w;
+            }
+            if (p.mask) {
+                const float4 mk = *reinterpret_cast<const float4*>(p.mask + pix * COUT + c4 * 4);
+                const float e = p.mask_elu ? 1.f : 0.f;
+                v.x = mk.x > 0.f ? v.x : e * v.x * (mk.x + 1.f); v.y = mk.y > 0.f ? v.y : e * v.y * (mk.y + 1.f);
+                v.z = mk.z > 0.f ? v.z : e * v.z * (mk.z + 1.f); v.w = mk.w > 0.f ? v.w : e * v.w * (mk.w + 1.f);
+            }
+            *reinterpret_cast<float4*>(p.Y + pix * COUT + c4 * 4) = v;
+        }
+        return;
+    }
     if (y >= p.H) return;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
