@@ -427,7 +427,7 @@ static int launch_tr(const GemmArgs& a, hipStream_t st) {
         case 128064: return launch_cfg<128, 64, AKC, BKC>(a, st);
         case 64128: return launch_cfg<64, 128, AKC, BKC>(a, st);
         case 64064: return launch_cfg<64, 64, AKC, BKC>(a, st);
-        case 128192: if (AKC) return launch_cfg<128, 192, AKC, BKC>(a, st); break;
+        case 128192: if (AKC || !BKC) return launch_cfg<128, 192, AKC, BKC>(a, st); break;
         default: break;
     }
     // measured on MI355X (tools/bench_gemm.py): 128-wide column tiles only pay when N is a multiple of 128;
@@ -435,6 +435,9 @@ static int launch_tr(const GemmArgs& a, hipStream_t st) {
     // long-K activation x weight products with N = 192 (the model width), e.g. the vocabulary-head dX: one 128x192 tile reads A
     // once and moves 38 FLOP per staged byte instead of 21 (+7 % measured at K = 4096; short K is faster on 128x64)
     if (AKC && a.N == 192 && a.K >= 1024 && a.M >= 4096) return launch_cfg<128, 192, AKC, BKC>(a, st);
+    // weight gradients with 192 input features (dW = dY^T X over >= 10^5 rows, split-K): a 128x192 tile reads X once per split
+    // (PMC: the 128x64 tiling moved 643 MB per launch for 201 MB of operands); single LDS buffer to keep two workgroups per CU
+    if (!AKC && !BKC && a.N == 192 && a.K >= 4096) return launch_cfg2<128, 192, AKC, BKC, true>(a, st);
     const bool wide = (a.N % 128 == 0);
     if (wide) {
         if (a.M > 64) return launch_cfg<128, 128, AKC, BKC>(a, st);
