@@ -154,6 +154,8 @@ void SlateModel::layout_workspace(bool commit) {
     sa_grows_ = carve(nullptr, BK * I * go.ld);
     sa_wts_ = carve(nullptr, wo.total);
     sa_small_ = carve(nullptr, B * (4 * D + 2 * C));
+    sa_xchg_ = carve(nullptr, B * sa_xchg_floats_host(K, D));
+    sa_counters_ = reinterpret_cast<int*>(carve(nullptr, (size_t)B * I + 64));
     sa_pack_dev_ = reinterpret_cast<PackEntry*>(carve(nullptr, 64 * sizeof(PackEntry) / 4 + 64));
     for (int i = 0; i < 4; ++i) {
         const int cin = i == 0 ? 8 : 64;
@@ -383,6 +385,7 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st) {
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
+    a.xchg = sa_xchg_; a.counters = sa_counters_;
     RC(slot_attn_launch(a, 0, st));
     return 0;
 }

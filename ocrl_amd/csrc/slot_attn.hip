@@ -23,6 +23,7 @@
 #include "kernels.h"
 
 #define SA_C 64
+#include <stdlib.h>
 #define SA_TF 1024        // forward threads per workgroup (16 waves)
 #define SA_TB 512         // backward threads per workgroup (8 waves)
 #define SA_TLD 68         // row stride of the per-wave [16 positions][64 channels] LDS tile
@@ -169,7 +170,7 @@ __device__ inline void sa_fold_affine(const float* v, const float* __restrict__ 
 // scr[wave][j][0..63] = sum_n w[n,j] xn[n],  scr[wave][j][64] = sum_n w[n,j]   (scr aliases the tiles: barrier inside)
 template <int K>
 __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int N, const float* qg, const float* qb, float eps, float* attn_out,
-                                              float* tiles, float* scr) {
+                                              float* tiles, float* scr, int tile0 = 0, int tile1 = -1) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
     float* tile = tiles + wv * 16 * SA_TLD;
     float qpr[16];
@@ -180,11 +181,11 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;
-    const int ntile = (N + 15) / 16;
+    const int ntile = tile1 < 0 ? (N + 15) / 16 : tile1;      // this workgroup's tiles: [tile0, ntile)
     // two register stages per wave: while tile t is processed, tiles t + nw and t + 2 nw are in flight
     float4 bufA[4], bufB[4];
-    if (wv < ntile) sa_load_tile(xb, N, wv, li, g, bufA);
-    if (wv + nw < ntile) sa_load_tile(xb, N, wv + nw, li, g, bufB);
+    if (tile0 + wv < ntile) sa_load_tile(xb, N, tile0 + wv, li, g, bufA);
+    if (tile0 + wv + nw < ntile) sa_load_tile(xb, N, tile0 + wv + nw, li, g, bufB);
     auto tile_step = [&](float4 (&cur)[4], int t) {
         float xn[16];
         sa_ln16(cur, xn);
@@ -216,7 +217,7 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
         __builtin_amdgcn_wave_barrier();
     };
 #pragma unroll 1
-    for (int t = wv; t < ntile; t += 2 * nw) {
+    for (int t = tile0 + wv; t < ntile; t += 2 * nw) {
         tile_step(bufA, t);
         if (t + nw < ntile) tile_step(bufB, t + nw);
     }
@@ -235,113 +236,212 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
 // temporaries (LN output, q, GRU gates, MLP hidden) are sized for KB rows and the kernel fits the 160 KB LDS up to K = 16.
 template <int K> struct SaBlk { static constexpr int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB; };
 
+// LDS map of the forward kernels
+template <int K>
+struct SaFwdLds {
+    float *s, *sn, *q, *u, *gi, *gh, *hid, *qp, *up, *qg, *cs, *qb, *tiles;
+    __device__ SaFwdLds(float* sm, int D, int H) {
+        constexpr int C = SA_C, KB = SaBlk<K>::KB, KP = SaBlk<K>::KP;
+        s = sm;                       // [KP][D] slots (rows >= K are padding)
+        sn = s + KP * D;              // [KB][D]
+        q = sn + KB * D;              // [KB][D]
+        u = q + KB * D;               // [KB][D]
+        gi = u + KB * D;              // [KB][3D]
+        gh = gi + KB * 3 * D;         // [KB][3D]
+        hid = gh + KB * 3 * D;        // [KB][H]
+        qp = hid + KB * H;            // [KP][C]
+        up = qp + KP * C;             // [KP][C]
+        qg = up + KP * C;             // [KP][C] gamma_in * q'
+        cs = qg + KP * C;             // [16] weight sums
+        qb = cs + 16;                 // [16] beta_in . q'
+        tiles = qb + 16;              // [waves][16][SA_TLD]: streaming tiles, reduction scratch
+    }
+};
+
+// slot side before the streaming pass of iteration t: LN(slots), q, q' = scale q Wk, and q' folded with the norm_inputs affine
+template <int K>
+__device__ __forceinline__ void sa_phase_a(const SaFwdLds<K>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, float* sv0) {
+    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB;
+    const int D = p.D;
+    const float* W = p.wts;
+#pragma unroll 1
+    for (int hb = 0; hb < NB; ++hb) {
+        const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+        float* sB = L.s + j0 * D;
+        float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
+        if (sv) rows_to_global(sB, sv + so.sprev, so.ld, kv, D);
+        ln_rows(sB, L.sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
+        __syncthreads();
+        matvec<KB>(W + wo.Wq, D, D, D, L.sn, D, L.q, D, nullptr, 1.f);
+        matvec<KB>(W + wo.WkT, D, D, C, L.q, D, L.qp + j0 * C, C, nullptr, p.scale);
+        if (sv) {
+            rows_to_global(L.sn, sv + so.sn, so.ld, kv, D);
+            rows_to_global(L.q, sv + so.q, so.ld, kv, D);
+            rows_to_global(L.qp + j0 * C, sv + so.qp, so.ld, kv, C);
+        }
+        __syncthreads();
+    }
+    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, K);
+    __syncthreads();
+}
+
+// weighted means from `nparts` partial sums part[w][j][0..63] = sum w xn, part[w][j][64] = sum w  (LDS or global memory)
+template <int K>
+__device__ __forceinline__ void sa_reduce_parts(const SaFwdLds<K>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const float* part, int nparts,
+                                                float* sv0) {
+    constexpr int C = SA_C;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float* W = p.wts;
+    if (tid < K) {
+        float c0 = 0.f;
+        for (int w = 0; w < nparts; ++w) c0 += part[(w * K + tid) * (C + 1) + C];
+        L.cs[tid] = c0;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * C; i += nt) {
+        const int j = i >> 6, c = i & 63;
+        float a = 0.f;
+        for (int w = 0; w < nparts; ++w) a += part[(w * K + j) * (C + 1) + c];
+        a /= L.cs[j];                                                  // sum_n w xn / sum_n w
+        const float v = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
+        L.up[i] = v;
+        if (sv0) { sv0[j * so.ld + so.upn + c] = a; sv0[j * so.ld + so.up + c] = v; }
+    }
+    if (sv0 && tid < K) sv0[tid * so.ld + so.csum] = L.cs[tid];
+    __syncthreads();
+}
+
+// slot side after the streaming pass: updates = U' Wv^T ; GRU ; residual MLP
+template <int K>
+__device__ __forceinline__ void sa_phase_u(const SaFwdLds<K>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, float* sv0) {
+    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB;
+    const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x;
+    const float* W = p.wts;
+    float *q = L.q, *u = L.u, *gi = L.gi, *gh = L.gh, *hid = L.hid, *sn = L.sn;
+#pragma unroll 1
+    for (int hb = 0; hb < NB; ++hb) {
+        const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+        float* sB = L.s + j0 * D;
+        float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
+        matvec<KB>(W + wo.Wv, C, C, D, L.up + j0 * C, C, u, D, nullptr, 1.f);
+        matvec<KB>(W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f);
+        matvec<KB>(W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f);
+        for (int i = tid; i < KB * D; i += nt) {
+            const int j = i / D, c = i - j * D;
+            const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
+            const float z = sigmoidf_(gi[j * 3 * D + D + c] + gh[j * 3 * D + D + c]);
+            const float hn = gh[j * 3 * D + 2 * D + c];
+            const float nn = tanhf(gi[j * 3 * D + 2 * D + c] + r * hn);
+            const float sg = (1.f - z) * nn + z * sB[i];
+            if (sv && j < kv) {
+                float* row = sv + j * so.ld + c;
+                row[so.u] = u[i]; row[so.r] = r; row[so.z] = z; row[so.n] = nn; row[so.hn] = hn; row[so.sg] = sg;
+            }
+            q[i] = sg;      // q is free now: holds s_gru
+        }
+        __syncthreads();
+        ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, KB, D);      // sn = m
+        __syncthreads();
+        matvec<KB>(W + wo.W0, D, D, H, sn, D, hid, H, W + wo.b0, 1.f);
+        for (int i = tid; i < KB * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
+        __syncthreads();
+        matvec<KB>(W + wo.W2, H, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
+        for (int i = tid; i < kv * D; i += nt) sB[i] = q[i] + u[i];
+        if (sv) {
+            rows_to_global(sn, sv + so.m, so.ld, kv, D);
+            rows_to_global(hid, sv + so.hid, so.ld, kv, H);
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per image, all iterations in one launch, slots resident in LDS throughout.
 template <int K>
 __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int D = p.D, H = p.H, N = p.N;
-    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB, KP = SaBlk<K>::KP;
-    const int nt = blockDim.x, nw = nt >> 6;
-    float* s = sm;                       // [KP][D] slots (rows >= K are padding)
-    float* sn = s + KP * D;              // [KB][D]
-    float* q = sn + KB * D;              // [KB][D]
-    float* u = q + KB * D;               // [KB][D]
-    float* gi = u + KB * D;              // [KB][3D]
-    float* gh = gi + KB * 3 * D;         // [KB][3D]
-    float* hid = gh + KB * 3 * D;        // [KB][H]
-    float* qp = hid + KB * H;            // [KP][C]
-    float* up = qp + KP * C;             // [KP][C]
-    float* qg = up + KP * C;             // [KP][C] gamma_in * q'
-    float* cs = qg + KP * C;             // [16] weight sums
-    float* qb = cs + 16;                 // [16] beta_in . q'
-    float* tiles = qb + 16;              // [waves][16][SA_TLD]: streaming tiles, matvec / reduction scratch
-
+    constexpr int C = SA_C, KP = SaBlk<K>::KP;
+    const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
+    const SaFwdLds<K> L(sm, D, p.H);
     const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const float* W = p.wts;
-    for (int i = tid; i < KP * D; i += nt) s[i] = i < K * D ? p.slots0[(size_t)b * K * D + i] : 0.f;
+    for (int i = tid; i < KP * D; i += nt) L.s[i] = i < K * D ? p.slots0[(size_t)b * K * D + i] : 0.f;
     __syncthreads();
     const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
-
     for (int t = 0; t < p.I; ++t) {
         float* sv0 = p.save ? p.save + ((size_t)b * p.I + t) * K * so.ld : nullptr;   // K rows of the save matrix
-        // ---- slot side: LN, q, q'
-#pragma unroll 1
-        for (int hb = 0; hb < NB; ++hb) {
-            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
-            float* sB = s + j0 * D;
-            float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
-            if (sv) rows_to_global(sB, sv + so.sprev, so.ld, kv, D);
-            ln_rows(sB, sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
-            __syncthreads();
-            matvec<KB>(W + wo.Wq, D, D, D, sn, D, q, D, nullptr, 1.f);
-            matvec<KB>(W + wo.WkT, D, D, C, q, D, qp + j0 * C, C, nullptr, p.scale);
-            if (sv) {
-                rows_to_global(sn, sv + so.sn, so.ld, kv, D);
-                rows_to_global(q, sv + so.q, so.ld, kv, D);
-                rows_to_global(qp + j0 * C, sv + so.qp, so.ld, kv, C);
-            }
-            __syncthreads();
-        }
-        sa_fold_affine(qp, W + wo.ln_in_g, W + wo.ln_in_b, qg, qb, K);
+        sa_phase_a<K>(L, p, wo, so, sv0);
+        sa_stream_fwd<K>(xb, N, L.qg, L.qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, L.tiles, L.tiles);
         __syncthreads();
-        // ---- streaming pass over the N positions
-        sa_stream_fwd<K>(xb, N, qg, qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, tiles, tiles);
-        __syncthreads();
-        if (tid < K) {
-            float c0 = 0.f;
-            for (int w = 0; w < nw; ++w) c0 += tiles[(w * K + tid) * (C + 1) + C];
-            cs[tid] = c0;
-        }
-        __syncthreads();
-        for (int i = tid; i < K * C; i += nt) {
-            const int j = i >> 6, c = i & 63;
-            float a = 0.f;
-            for (int w = 0; w < nw; ++w) a += tiles[(w * K + j) * (C + 1) + c];
-            a /= cs[j];                                                  // sum_n w xn / sum_n w
-            const float v = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
-            up[i] = v;
-            if (sv0) { sv0[j * so.ld + so.upn + c] = a; sv0[j * so.ld + so.up + c] = v; }
-        }
-        if (sv0 && tid < K) sv0[tid * so.ld + so.csum] = cs[tid];
-        __syncthreads();
-        // ---- updates = U' Wv^T ; GRU ; residual MLP
-#pragma unroll 1
-        for (int hb = 0; hb < NB; ++hb) {
-            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
-            float* sB = s + j0 * D;
-            float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
-            matvec<KB>(W + wo.Wv, C, C, D, up + j0 * C, C, u, D, nullptr, 1.f);
-            matvec<KB>(W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f);
-            matvec<KB>(W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f);
-            for (int i = tid; i < KB * D; i += nt) {
-                const int j = i / D, c = i - j * D;
-                const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
-                const float z = sigmoidf_(gi[j * 3 * D + D + c] + gh[j * 3 * D + D + c]);
-                const float hn = gh[j * 3 * D + 2 * D + c];
-                const float nn = tanhf(gi[j * 3 * D + 2 * D + c] + r * hn);
-                const float sg = (1.f - z) * nn + z * sB[i];
-                if (sv && j < kv) {
-                    float* row = sv + j * so.ld + c;
-                    row[so.u] = u[i]; row[so.r] = r; row[so.z] = z; row[so.n] = nn; row[so.hn] = hn; row[so.sg] = sg;
-                }
-                q[i] = sg;      // q is free now: holds s_gru
-            }
-            __syncthreads();
-            ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, KB, D);      // sn = m
-            __syncthreads();
-            matvec<KB>(W + wo.W0, D, D, H, sn, D, hid, H, W + wo.b0, 1.f);
-            for (int i = tid; i < KB * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
-            __syncthreads();
-            matvec<KB>(W + wo.W2, H, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
-            for (int i = tid; i < kv * D; i += nt) sB[i] = q[i] + u[i];
-            if (sv) {
-                rows_to_global(sn, sv + so.m, so.ld, kv, D);
-                rows_to_global(hid, sv + so.hid, so.ld, kv, H);
-            }
-            __syncthreads();
-        }
+        sa_reduce_parts<K>(L, p, wo, so, L.tiles, nw, sv0);
+        sa_phase_u<K>(L, p, wo, so, sv0);
     }
-    for (int i = tid; i < K * D; i += nt) p.slots[(size_t)b * K * D + i] = s[i];
+    for (int i = tid; i < K * D; i += nt) p.slots[(size_t)b * K * D + i] = L.s[i];
+}
+
+// Split form for batches that leave CUs idle (B < #CUs): NS workgroups per image and ONE LAUNCH PER ITERATION.  Every workgroup
+// streams 1/NS of the positions and writes its partial sums; the workgroup that arrives last at the image's counter (agent-scope
+// release / acquire around one atomic, no waiting on anybody) reduces the partials, runs the slot update and prepares q' of the
+// next iteration.  Between launches an image's slots and folded query live in `xchg` (a few KB per image); within a launch they
+// are in LDS as in the fused kernel.  t = -1 is the preparation launch (one workgroup per image: q' of iteration 0).
+//   xchg per image: slots [KP*D] | qg [KP*64] | qb [16] | parts [NS][K][65]
+__host__ __device__ inline size_t sa_xchg_floats(int K, int D, int NS) {
+    const int KP = K > 8 ? 2 * ((K + 1) / 2) : K;
+    return (size_t)KP * D + (size_t)KP * SA_C + 16 + (size_t)NS * K * (SA_C + 1) + 15;
+}
+template <int K>
+__global__ __launch_bounds__(SA_TF) void slot_attn_fwd_split_kernel(SlotAttnArgs p, SaWts wo, SaSave so, int t, int NS) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = SA_C, KP = SaBlk<K>::KP;
+    const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
+    const SaFwdLds<K> L(sm, D, p.H);
+    const int b = t < 0 ? blockIdx.x : blockIdx.x / NS, h = t < 0 ? 0 : blockIdx.x % NS;
+    float* xg = p.xchg + (size_t)b * sa_xchg_floats(K, D, NS);
+    float* g_slots = xg;
+    float* g_qg = g_slots + KP * D;
+    float* g_qb = g_qg + KP * C;
+    float* g_parts = g_qb + 16;
+    if (t < 0) {
+        for (int i = tid; i < KP * D; i += nt) L.s[i] = i < K * D ? p.slots0[(size_t)b * K * D + i] : 0.f;
+        __syncthreads();
+        sa_phase_a<K>(L, p, wo, so, p.save ? p.save + (size_t)b * p.I * K * so.ld : nullptr);
+        for (int i = tid; i < KP * D; i += nt) g_slots[i] = L.s[i];
+        for (int i = tid; i < K * C; i += nt) g_qg[i] = L.qg[i];
+        if (tid < K) g_qb[tid] = L.qb[tid];
+        return;
+    }
+    for (int i = tid; i < K * C; i += nt) L.qg[i] = g_qg[i];
+    if (tid < K) L.qb[tid] = g_qb[tid];
+    __syncthreads();
+    const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
+    const int ntile = (N + 15) / 16, per = (ntile + NS - 1) / NS;
+    const int t0 = h * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
+    sa_stream_fwd<K>(xb, N, L.qg, L.qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, L.tiles, L.tiles, t0, t1 > t0 ? t1 : t0);
+    __syncthreads();
+    for (int i = tid; i < K * (C + 1); i += nt) {          // this workgroup's partial: sum over its waves
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += L.tiles[w * K * (C + 1) + i];
+        g_parts[(size_t)h * K * (C + 1) + i] = a;
+    }
+    __threadfence();                                       // release (agent scope) of every thread's share of the partial ...
+    __syncthreads();                                       // ... ordered before the count below; the tile region is free again
+    int* s_last = reinterpret_cast<int*>(L.tiles);
+    if (tid == 0) *s_last = atomicAdd(&p.counters[(size_t)b * p.I + t], 1) == NS - 1;
+    __syncthreads();
+    if (!*s_last) return;
+    __syncthreads();
+    __threadfence();                                       // acquire: the other workgroups' partials
+    float* sv0 = p.save ? p.save + ((size_t)b * p.I + t) * K * so.ld : nullptr;
+    for (int i = tid; i < KP * D; i += nt) L.s[i] = g_slots[i];
+    __syncthreads();
+    sa_reduce_parts<K>(L, p, wo, so, g_parts, NS, sv0);
+    sa_phase_u<K>(L, p, wo, so, sv0);
+    if (t == p.I - 1) {
+        for (int i = tid; i < K * D; i += nt) p.slots[(size_t)b * K * D + i] = L.s[i];
+        return;
+    }
+    sa_phase_a<K>(L, p, wo, so, p.save ? p.save + ((size_t)b * p.I + t + 1) * K * so.ld : nullptr);
+    for (int i = tid; i < KP * D; i += nt) g_slots[i] = L.s[i];
+    for (int i = tid; i < K * C; i += nt) g_qg[i] = L.qg[i];
+    if (tid < K) g_qb[tid] = L.qb[tid];
 }
 
 // ------------------------------------------------------------------------------------------- backward streaming pass
@@ -635,10 +735,29 @@ static size_t sa_fwd_smem(int K, int D, int H) {
     const size_t tiles = (size_t)(SA_TF / 64) * 16 * SA_TLD;
     return (size_t)(KP * D + KB * D * 3 + KB * 3 * D * 2 + KB * H + KP * SA_C * 3 + 32 + tiles) * 4;
 }
+size_t sa_xchg_floats_host(int K, int D) { return sa_xchg_floats(K, D, SA_MAX_SPLIT); }
 static size_t sa_bwd_smem(int K, int D, int H) {
     const int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB;
     const size_t tiles = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
     return (size_t)(KP * D * 2 + KB * D * 2 + KB * 3 * D * 2 + KB * H + KP * SA_C * 5 + 80 + 4 * D + 2 * SA_C + tiles) * 4;
+}
+
+// workgroups per image of the split forward: fill the CUs (one workgroup per CU: the kernel owns most of the LDS), at least 32
+// tiles per workgroup; 1 = fused single-launch kernel.  OCRL_SA_SPLIT=0 disables the split form.
+int sa_fwd_splits(const SlotAttnArgs& a) {
+    static int ncu = 0, mode = -1;
+    if (mode < 0) { const char* e = getenv("OCRL_SA_SPLIT"); mode = e ? atoi(e) : 1; }
+    if (!mode || !a.xchg || !a.counters) return 1;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
+        ncu = prop.multiProcessorCount;
+    }
+    int ns = 1;
+    const int ntile = (a.N + 15) / 16;
+    while (ns < SA_MAX_SPLIT && a.B * ns * 2 <= ncu && ntile / (ns * 2) >= 32) ns *= 2;
+    return ns;
 }
 
 template <int K>
@@ -660,8 +779,16 @@ static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
         OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_bwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((slot_attn_bwd_kernel<K>), dim3(a.B), dim3(SA_TB), smem, st, a, wo, so, go);
     } else {
-        OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((slot_attn_fwd_kernel<K>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so);
+        const int NS = sa_fwd_splits(a);
+        if (NS > 1) {
+            OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_split_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            OCRL_HIP(hipMemsetAsync(a.counters, 0, sizeof(int) * (size_t)a.B * a.I, st));
+            hipLaunchKernelGGL((slot_attn_fwd_split_kernel<K>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
+            for (int t = 0; t < a.I; ++t) hipLaunchKernelGGL((slot_attn_fwd_split_kernel<K>), dim3(a.B * NS), dim3(SA_TF), smem, st, a, wo, so, t, NS);
+        } else {
+            OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((slot_attn_fwd_kernel<K>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so);
+        }
     }
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("slot_attn");

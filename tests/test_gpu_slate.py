@@ -90,7 +90,9 @@ def test_forward_backward_eval(tag, over, B):
     P = O.formula_params(cfg)
     eng = make_engine(cfg, B)
     load_params(eng, P)
-    g = torch.Generator().manual_seed(100)
+    # seed 100 puts one FFN pre-activation of the "mid" case at 6e-7: a ReLU on the rounding knife-edge, whose mask (and with it a
+    # whole gradient row) flips with the summation order of the slot means.  Seed 102 keeps every pre-activation above 5e-6.
+    g = torch.Generator().manual_seed(102 if tag == "mid" else 100)
     obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=g)
     noise = O.make_noise(cfg, B, 7)
     step = 10
