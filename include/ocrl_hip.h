@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define OCRL_ABI_VERSION 3
+#define OCRL_ABI_VERSION 4
 
 const char* ocrl_last_error(void);
 int ocrl_abi_version(void);
@@ -136,6 +136,27 @@ int ocrl_slot_attention_fwd(const float* x, const float* slots0, const float* co
                             int H, int I, float* ws, size_t ws_floats, void* stream);
 int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H,
                             int I, float* ws, size_t ws_floats, void* stream);
+
+/* ---- slot-set pooling head: poolings/common/transformer.py:9-33 (Transformer: Linear -> [CLS; tokens] (+pos) ->
+ * nn.TransformerEncoder of post-norm ReLU layers -> CLS row), as built by poolings/transformer/transformer_module.py:27-117 with its
+ * default switches; the consumer of the slots in sb3s/ocr_extractor.py:45.  SURVEY.md §8(f) rank 4.
+ * slots [B,K,Din]; `w` = 3 + 12 L device pointers in the module's state_dict order: _linear.{weight [d,Din], bias},
+ * _cls_token._cls_token [d], then per layer self_attn.in_proj_{weight [3d,d], bias}, self_attn.out_proj.{weight,bias},
+ * linear1.{weight [ff,d], bias}, linear2.{weight [d,ff], bias}, norm1.{weight,bias}, norm2.{weight,bias}.
+ * pos: [K+1,d] positional table added to the token sequence (the reference's `pe` buffers), or NULL (pos_emb "None").
+ * out [B,d] = encoder output of the CLS token.  drop_p = nn.TransformerEncoderLayer's dropout in train mode (0 in eval); the keep
+ * decisions are a pure function of (seed, layer, site, element) so _bwd regenerates them: pass the same drop_p and seed.
+ * _bwd: dout [B,d] -> dw (same order / shapes as w; every entry is overwritten) and dslots [B,K,Din] (NULL = the slots are detached,
+ * poolings/base.py:53).  Call it with the same ws right after _fwd.  d_model: multiple of 64 up to 256; K + 1 <= 32. */
+#define OCRL_POOL_MAX_LAYERS 8
+size_t ocrl_pool_transformer_ws_floats(int B, int K, int d, int nhead, int ff, int L);
+int ocrl_pool_transformer_fwd(const float* slots, const float* const* w, const float* pos, float* out, int B, int K, int Din, int d, int nhead,
+                              int ff, int L, float drop_p, unsigned long long seed, float* ws, size_t ws_floats, void* stream);
+int ocrl_pool_transformer_bwd(const float* slots, const float* dout, const float* const* w, float* dslots, float* const* dw, int B, int K, int Din,
+                              int d, int nhead, int ff, int L, float drop_p, unsigned long long seed, float* ws, size_t ws_floats, void* stream);
+/* keep-mask (1 = kept) of one dropout site, for parity tests: which = 0 attention weights [B,h,S,S], 1 dropout1 [B,S,d],
+ * 2 FFN hidden [B,S,ff], 3 dropout2 [B,S,d]; n = element count. */
+int ocrl_pool_transformer_dropout_mask(int layer, int which, long long n, float drop_p, unsigned long long seed, float* out, void* stream);
 
 /* ---- IODINE (ocrs/iodine/iodine_module.py:14-271, ocrs/iodine/iodine.py:4-14, ocrs/base.py:60-74): SURVEY.md §8 row a20 ----
  * Same conventions as the SLATE handle: flat fp32 parameter / gradient / Adam buffers in the reference's

@@ -88,13 +88,19 @@ def lib():
     L.ocrl_slot_attention_ws_floats.restype = c_size_t
     L.ocrl_slot_attention_fwd.argtypes = [p, p, POINTER(p), p, p, c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
     L.ocrl_slot_attention_bwd.argtypes = [p, p, p, p, POINTER(p), c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
+    L.ocrl_pool_transformer_ws_floats.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int]
+    L.ocrl_pool_transformer_ws_floats.restype = c_size_t
+    L.ocrl_pool_transformer_fwd.argtypes = [p, POINTER(p), p, p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, p, c_size_t, p]
+    L.ocrl_pool_transformer_bwd.argtypes = [p, p, POINTER(p), p, POINTER(p), c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, p,
+                                            c_size_t, p]
+    L.ocrl_pool_transformer_dropout_mask.argtypes = [c_int, c_int, c_longlong, c_float, c_ulonglong, p, p]
     L.ocrl_comm_unique_id.argtypes = [p, c_size_t]
     L.ocrl_comm_init.argtypes = [POINTER(p), c_int, c_int, p]
     L.ocrl_comm_allreduce.argtypes = [p, p, c_longlong, p]
     L.ocrl_comm_world.argtypes = [p]
     L.ocrl_comm_destroy.argtypes = [p]
     L.ocrl_comm_destroy.restype = None
-    if L.ocrl_abi_version() != 3:
+    if L.ocrl_abi_version() != 4:
         raise RuntimeError("libocrl_hip.so ABI version mismatch")
     _lib = L
     return L

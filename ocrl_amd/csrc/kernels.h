@@ -43,6 +43,12 @@ int gemm_launch(const GemmArgs& a, hipStream_t st);
 int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
                          int accumulate, hipStream_t st);
 
+// ------------------------------------------------------------------ pool.hip
+int pool_embed_launch(const float* lin, const float* cls, const float* pos, float* x0, int B, int K, int d, hipStream_t st);
+int pool_rows_launch(const float* in, float* out, int B, int K, int d, int mode, hipStream_t st);
+int pool_attn_launch(const float* qkv, float* P, float* O, const float* dO, float* dqkv, int B, int S, int d, int h, float p, unsigned long long seed,
+                     unsigned site, int backward, hipStream_t st);
+
 // ------------------------------------------------------------------ conv.hip
 struct ConvArgs {
     const float* X = nullptr;       // [B,H,W,CIN] NHWC

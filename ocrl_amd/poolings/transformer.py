@@ -1,0 +1,131 @@
+"""Transformer pooling (poolings/transformer/transformer.py:6-9, transformer_module.py:27-117, poolings/common/transformer.py:9-33).
+
+``Transformer_Module`` holds the parameters in torch containers of the reference's own structure (nn.Linear, ClsToken,
+nn.TransformerEncoder) so that ``state_dict()`` keys, shapes and initialisation are the reference's and its checkpoints load
+unchanged -- but their ``forward`` is never called: the arithmetic is ``ocrl_pool_transformer_fwd/_bwd`` (HIP), wrapped in a
+``torch.autograd.Function`` because in the reference the pooling parameters belong to the RL policy's torch optimiser
+(sb3s/ocr_extractor.py:33-35).  No CPU fallback: a CPU tensor raises."""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .base import Base
+
+
+class _ClsToken(nn.Module):
+    def __init__(self, emb_size):
+        super().__init__()
+        self._cls_token = nn.Parameter(torch.zeros(emb_size))
+
+
+class _PositionalEncoding(nn.Module):
+    """poolings/common/transformer.py:60-82 (sin/cos * 0.001, a buffer) and :85-127 (stacked observations)"""
+
+    def __init__(self, max_len, d_model, num_stacked_obss=1):
+        super().__init__()
+        if num_stacked_obss > 1:
+            assert (max_len - 1) % num_stacked_obss == 0
+            position = torch.arange((max_len - 1) // num_stacked_obss).repeat_interleave(num_stacked_obss)
+            position = torch.cat([torch.tensor([0]), position + 1], dim=0).unsqueeze(1)
+        else:
+            position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, 1, d_model)
+        pe[:, 0, 0::2] = torch.sin(position * div_term) * 0.001
+        pe[:, 0, 1::2] = torch.cos(position * div_term) * 0.001
+        self.register_buffer("pe", pe)
+
+
+class _PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, slots, pos, geom, drop_p, seed, *params):
+        if not slots.is_cuda:
+            raise RuntimeError("ocrl_amd.poolings: tensors must live on the GPU (there is no CPU fallback)")
+        L = _lib.lib()
+        d, nhead, ff, nl = geom
+        B, K, Din = slots.shape
+        slots = slots.contiguous().float()
+        ps = [p.detach().contiguous() for p in params]
+        n = L.ocrl_pool_transformer_ws_floats(B, K, d, nhead, ff, nl)
+        ws = torch.empty(n, device=slots.device, dtype=torch.float32)
+        out = torch.empty(B, d, device=slots.device, dtype=torch.float32)
+        arr = (ctypes.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.ocrl_pool_transformer_fwd(_lib.ptr(slots), arr, _lib.ptr(pos), _lib.ptr(out), B, K, Din, d, nhead, ff, nl, drop_p, seed, _lib.ptr(ws), n, st))
+        ctx.geom, ctx.drop_p, ctx.seed, ctx.ws, ctx.ps, ctx.slots = geom, drop_p, seed, ws, ps, slots
+        ctx.need_dslots = slots.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        d, nhead, ff, nl = ctx.geom
+        B, K, Din = ctx.slots.shape
+        dout = dout.contiguous().float()
+        gs = [torch.empty_like(p) for p in ctx.ps]
+        ds = torch.empty_like(ctx.slots) if ctx.need_dslots else None
+        arr = (ctypes.c_void_p * len(ctx.ps))(*[p.data_ptr() for p in ctx.ps])
+        garr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.ocrl_pool_transformer_bwd(_lib.ptr(ctx.slots), _lib.ptr(dout), arr, _lib.ptr(ds), garr, B, K, Din, d, nhead, ff, nl, ctx.drop_p, ctx.seed,
+                                               _lib.ptr(ctx.ws), ctx.ws.numel(), st))
+        return (ds, None, None, None, None, *gs)
+
+
+class _Transformer(nn.Module):
+    """parameter container with the reference's names: _linear, _cls_token, _pos, _trans (poolings/common/transformer.py:9-19)"""
+
+    def __init__(self, in_dim, d_model, nhead, num_layers, pos=None):
+        super().__init__()
+        self._linear = nn.Linear(in_dim, d_model)
+        self._cls_token = _ClsToken(d_model)
+        self._pos = pos
+        self._trans = nn.TransformerEncoder(nn.TransformerEncoderLayer(d_model, nhead), num_layers, enable_nested_tensor=False)
+
+
+class Transformer_Module(nn.Module):
+    def __init__(self, ocr_rep_dim: int, ocr_num_slots: int, config, num_stacked_obss: int = 1) -> None:
+        super().__init__()
+        self.rep_dim = d_model = config.d_model
+        self.config = config
+        for flag in ("use_mlp1", "use_mlp2", "cw_embedding", "push_embedding"):
+            if getattr(config, flag, False):
+                raise NotImplementedError(f"pooling.{flag}=True is not built in this backend (transformer_module.py:47-78)")
+        if num_stacked_obss > 1:
+            pos = _PositionalEncoding(ocr_num_slots * num_stacked_obss + 1, d_model, num_stacked_obss)
+        elif config.pos_emb in ("ape", "lpe"):           # both map to the fixed table in the reference (transformer_module.py:40-43)
+            pos = _PositionalEncoding(ocr_num_slots + 1, d_model)
+        elif config.pos_emb == "None":
+            pos = None
+        else:
+            raise ValueError(f"unknown pos_emb {config.pos_emb!r}")
+        self._trans = _Transformer(ocr_rep_dim, d_model, config.nhead, config.num_layers, pos)
+        layer = self._trans._trans.layers[0]
+        self._geom = (d_model, config.nhead, layer.linear1.out_features, config.num_layers)
+        self._drop_p = float(layer.dropout.p)
+        self._calls = 0
+        self.seed = 0
+
+    def _param_list(self):
+        t = self._trans
+        ps = [t._linear.weight, t._linear.bias, t._cls_token._cls_token]
+        for l in t._trans.layers:
+            ps += [l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias,
+                   l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
+        return ps
+
+    def forward(self, state):
+        pos = None if self._trans._pos is None else self._trans._pos.pe[: state.shape[1] + 1, 0].contiguous()
+        p = self._drop_p if self.training else 0.0
+        self._calls += 1
+        seed = (int(self.seed) << 32) + self._calls           # a fresh dropout pattern per call, reproducible from `seed`
+        return _PoolFn.apply(state, pos, self._geom, p, seed, *self._param_list())
+
+
+class Transformer(Base):
+    def __init__(self, ocr, config, num_stacked_obss: int = 1) -> None:
+        self._module = Transformer_Module(ocr.rep_dim, ocr.num_slots, config, num_stacked_obss)
+        super().__init__(ocr, config)

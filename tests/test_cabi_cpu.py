@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.ocrl_abi_version() == 3
+    assert L.ocrl_abi_version() == 4
 
 
 @pytest.mark.parametrize("over", [dict(obs_size=64), dict(obs_size=128, num_slots=6), dict(obs_size=16, vocab_size=256, num_dec_blocks=2),

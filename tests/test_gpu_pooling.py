@@ -1,0 +1,197 @@
+"""GPU parity of the slot-set pooling head (ocrl_pool_transformer_*) against oracle/pooling_oracle.py and the
+reference fixtures, through the C ABI and through the drop-in ``poolings`` Python surface."""
+import ctypes
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pooling_oracle as PO
+from tests.gpu_util import log, relerr
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run_hip(cfg, P, slots, cot, p_drop=0.0, seed=0, want_dslots=True):
+    from ocrl_amd import _lib
+    L = _lib.lib()
+    B, K, Din = slots.shape
+    d, h, ff, nl = cfg.d_model, cfg.nhead, cfg.dim_feedforward, cfg.num_layers
+    names = [n for n, _ in PO.param_shapes(cfg)]
+    w = [P[n].cuda().contiguous() for n in names]
+    g = [torch.full_like(t, float("nan")) for t in w]
+    pe = PO.pos_table(cfg)
+    pos = None if pe is None else pe.cuda().contiguous()
+    xs, dc = slots.cuda().contiguous(), cot.cuda().contiguous()
+    out = torch.empty(B, d, device="cuda")
+    ds = torch.full_like(xs, float("nan")) if want_dslots else None
+    n = L.ocrl_pool_transformer_ws_floats(B, K, d, h, ff, nl)
+    ws = torch.empty(n, device="cuda")
+    arr = (ctypes.c_void_p * len(w))(*[t.data_ptr() for t in w])
+    garr = (ctypes.c_void_p * len(g))(*[t.data_ptr() for t in g])
+    _lib.check(L.ocrl_pool_transformer_fwd(_lib.ptr(xs), arr, _lib.ptr(pos), _lib.ptr(out), B, K, Din, d, h, ff, nl, p_drop, seed, _lib.ptr(ws), n, None))
+    _lib.check(L.ocrl_pool_transformer_bwd(_lib.ptr(xs), _lib.ptr(dc), arr, _lib.ptr(ds), garr, B, K, Din, d, h, ff, nl, p_drop, seed, _lib.ptr(ws), n, None))
+    torch.cuda.synchronize()
+    return out.cpu(), dict(zip(names, [t.cpu() for t in g])), None if ds is None else ds.cpu()
+
+
+def hip_masks(cfg, B, p_drop, seed):
+    from ocrl_amd import _lib
+    L = _lib.lib()
+    S, d, ff, h = cfg.num_slots + 1, cfg.d_model, cfg.dim_feedforward, cfg.nhead
+    masks = {}
+    for l in range(cfg.num_layers):
+        for which, (key, shape) in enumerate((("attn", (B, h, S, S)), ("drop1", (B, S, d)), ("ffn", (B, S, ff)), ("drop2", (B, S, d)))):
+            m = torch.empty(shape, device="cuda")
+            _lib.check(L.ocrl_pool_transformer_dropout_mask(l, which, m.numel(), p_drop, seed, _lib.ptr(m), None))
+            masks[f"l{l}.{key}"] = m.cpu()
+    return masks
+
+
+def compare(tag, cfg, got, ref, tol_out=2e-5, tol_g=3e-4):
+    out, g, ds = got
+    r_out, r_g, r_ds = ref
+    e_out = relerr(out, r_out)
+    gmax = max(v.abs().max().item() for v in r_g.values())
+    rows = sorted(((relerr(g[n], r_g[n], floor=1e-4 * gmax), n) for n in r_g), reverse=True)
+    e_ds = relerr(ds, r_ds) if ds is not None else 0.0
+    log(f"[pool {tag}] out {e_out:.2e} dslots {e_ds:.2e} grads worst {rows[0][0]:.2e} ({rows[0][1]})")
+    assert e_out < tol_out, e_out
+    assert e_ds < tol_g, e_ds
+    assert rows[0][0] < tol_g, rows[:4]
+
+
+CASES = [("default", dict(), 3), ("ape_l2", dict(rep_dim=64, num_slots=4, num_layers=2, pos_emb="ape", nhead=4), 2),
+         ("k16_b32", dict(num_slots=16, dim_feedforward=512), 32), ("k1", dict(num_slots=1, rep_dim=64, dim_feedforward=256), 5),
+         ("d256_h4", dict(d_model=256, nhead=4, dim_feedforward=512, num_layers=3), 4), ("h16", dict(nhead=16, dim_feedforward=256), 2)]
+
+
+@pytest.mark.parametrize("tag,over,B", CASES)
+def test_eval_matches_oracle(tag, over, B):
+    cfg = PO.default_cfg(**over)
+    P = PO.formula_params(cfg)
+    g = torch.Generator().manual_seed(11)
+    slots = torch.randn(B, cfg.num_slots, cfg.rep_dim, generator=g)
+    cot = torch.randn(B, cfg.d_model, generator=g)
+    compare(tag, cfg, run_hip(cfg, P, slots, cot), PO.loss_and_grads(P, slots, cfg, cot))
+
+
+@pytest.mark.parametrize("tag", ["default", "ape_l2"])
+def test_eval_matches_reference_fixture(tag):
+    """straight against the numbers the reference module produced (tests/golden/make_golden_pooling.py)"""
+    fx = np.load(os.path.join(GOLD, f"pooling_{tag}.npz"))
+    rep, K, d, nhead, L, ff, has_pos, B = [int(v) for v in fx["cfg"]]
+    cfg = PO.default_cfg(rep_dim=rep, num_slots=K, d_model=d, nhead=nhead, num_layers=L, dim_feedforward=ff, pos_emb="ape" if has_pos else "None")
+    out, g, ds = run_hip(cfg, PO.formula_params(cfg), torch.from_numpy(fx["slots"]), torch.from_numpy(fx["cot"]))
+    assert relerr(out, torch.from_numpy(fx["out"])) < 2e-5
+    assert relerr(ds, torch.from_numpy(fx["dslots"])) < 3e-4
+    gmax = max(np.abs(fx["g:" + n][3:]).max() for n in g)
+    for n, t in g.items():
+        t = t.double().flatten()
+        sample = t[:: max(1, t.numel() // 509)][:509].numpy()
+        assert np.abs(sample - fx["g:" + n][3:]).max() < 3e-4 * max(np.abs(fx["g:" + n][3:]).max(), 1e-3 * gmax), n
+
+
+@pytest.mark.parametrize("tag,over,B", [CASES[0], CASES[1], CASES[2]])
+def test_train_mode_dropout_parity(tag, over, B):
+    """train mode: the oracle consumes the exact keep-masks the kernels derive from (seed, layer, site)"""
+    cfg = PO.default_cfg(**over)
+    P = PO.formula_params(cfg)
+    g = torch.Generator().manual_seed(5)
+    slots = torch.randn(B, cfg.num_slots, cfg.rep_dim, generator=g)
+    cot = torch.randn(B, cfg.d_model, generator=g)
+    p, seed = cfg.dropout, 0x1234567800000009
+    masks = hip_masks(cfg, B, p, seed)
+    keep = np.mean([m.mean().item() for m in masks.values()])
+    assert abs(keep - (1 - p)) < 0.02, keep
+    compare(tag + "/train", cfg, run_hip(cfg, P, slots, cot, p, seed), PO.loss_and_grads(P, slots, cfg, cot, masks, p))
+
+
+def test_detached_slots_and_bad_arguments():
+    from ocrl_amd import _lib
+    cfg = PO.default_cfg()
+    P = PO.formula_params(cfg)
+    slots, cot = torch.randn(2, 6, 192), torch.randn(2, 128)
+    out, g, ds = run_hip(cfg, P, slots, cot, want_dslots=False)
+    assert ds is None and all(torch.isfinite(t).all() for t in g.values())
+    L = _lib.lib()
+    assert L.ocrl_pool_transformer_fwd(None, None, None, None, 2, 6, 192, 128, 8, 2048, 1, 0.0, 0, None, 0, None) != 0
+    x = torch.zeros(8, device="cuda")
+    arr = (ctypes.c_void_p * 15)(*[x.data_ptr()] * 15)
+    assert L.ocrl_pool_transformer_fwd(_lib.ptr(x), arr, None, _lib.ptr(x), 2, 40, 192, 128, 8, 2048, 1, 0.0, 0, _lib.ptr(x), 8, None) != 0
+    assert b"num_slots" in L.ocrl_last_error()
+    assert L.ocrl_pool_transformer_fwd(_lib.ptr(x), arr, None, _lib.ptr(x), 2, 6, 192, 128, 8, 2048, 1, 0.0, 0, _lib.ptr(x), 8, None) != 0
+    assert b"workspace" in L.ocrl_last_error()
+
+
+def _pool_cfg(**over):
+    c = types.SimpleNamespace(name="Transformer", rep_dim=128, d_model=128, nhead=8, num_layers=1, pos_emb="None", norm_first=False, use_mlp1=False,
+                              use_mlp2=False, cw_embedding=False, push_embedding=False, learn_aux_loss=False, learn_downstream_loss=False,
+                              ocr_checkpoint=types.SimpleNamespace(run_id="", local_file=""), learning=types.SimpleNamespace(lr=1e-3))
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_python_surface_trains_with_a_torch_optimizer():
+    """Transformer_Module: reference state_dict keys, autograd through the HIP kernels, torch.optim.Adam on its parameters"""
+    from ocrl_amd.poolings import Transformer_Module
+    cfg = PO.default_cfg()
+    m = Transformer_Module(cfg.rep_dim, cfg.num_slots, _pool_cfg()).cuda()
+    assert list(m.state_dict()) == [n for n, _ in PO.param_shapes(cfg)]
+    P = PO.formula_params(cfg)
+    m.load_state_dict(P)
+    g = torch.Generator().manual_seed(3)
+    slots = torch.randn(4, cfg.num_slots, cfg.rep_dim, generator=g)
+    target = torch.randn(4, cfg.d_model, generator=g)
+    m.eval()
+    out = m(slots.cuda())
+    assert relerr(out, PO.forward(P, slots, cfg)) < 2e-5
+    with pytest.raises(RuntimeError):
+        m(slots)                                                    # CPU tensor: no fallback
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = ((m(slots.cuda()) - target.cuda()) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.8 * losses[0], losses
+    a, b = m(slots.cuda()), m(slots.cuda())
+    assert (a - b).abs().max().item() > 0                           # train mode: a fresh dropout pattern per call
+    m.eval()
+    assert (m(slots.cuda()) - m(slots.cuda())).abs().max().item() == 0
+
+
+def test_pooling_wrapper_and_extractor_over_the_encoder():
+    """poolings.Transformer(ocr, config) and OCRExtractor: observations -> SLATE encoder slots -> pooling vector, all on the HIP path"""
+    from ocrl_amd import ocrs, poolings
+    from ocrl_amd.sb3s import OCRExtractor
+    from ocrl_amd.utils.config import compose
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ocr_cfg = compose(os.path.join(root, "configs"), "train_ocr", ["ocr=slate", "ocr.slotattr.num_slots=5", "ocr.dvae.vocab_size=256",
+                                                                     "ocr.tfdec.num_dec_blocks=1", "dataset=random-N5C4S4S2", "dataset.obs_size=32"])
+    ocr = ocrs.SLATE(ocr_cfg.ocr, ocr_cfg.dataset)
+    ocr.to("cuda:0")
+    pool = poolings.Transformer(ocr, _pool_cfg())
+    pool.to("cuda:0")
+    pool.eval()
+    obs = torch.rand(4, 3, 32, 32, device="cuda")
+    v = pool(obs)
+    assert v.shape == (4, 128) and torch.isfinite(v).all()
+    slots = ocr(obs)                                                # fresh slot noise per call: pool the same slots on both sides
+    P = {k: t.detach().cpu() for k, t in pool._module.state_dict().items()}
+    cfg = PO.default_cfg(num_slots=5, rep_dim=ocr.rep_dim)
+    assert relerr(pool._module(slots), PO.forward(P, slots.cpu(), cfg)) < 2e-5
+    ck = pool.save()
+    assert "pooling_module_state_dict" in ck and "ocr_module_state_dict" in ck
+    full = types.SimpleNamespace(ocr=ocr_cfg.ocr, env=ocr_cfg.dataset, pooling=_pool_cfg(), num_envs=4, device="cuda:0")
+    ex = OCRExtractor(None, full).to("cuda:0")
+    ex.eval()
+    f = ex(obs)
+    assert f.shape == (4, ex.features_dim) and torch.isfinite(f).all()

@@ -151,3 +151,37 @@ def test_iodine_oracle_matches_reference(golden_dir, tag, over):
     for n, ref in zip([str(n) for n in fx["grad_names"]], fx["grad_sums"]):
         np.testing.assert_allclose(_summ(grads[n])[1:], ref[1:], rtol=1e-4, atol=1e-6 * gmax, err_msg=n)
         np.testing.assert_allclose(grads[n].flatten()[:16].numpy(), fx["gradhead." + n], rtol=2e-4, atol=1e-6 * gmax, err_msg=n)
+
+
+# ----------------------------------------------------------------------------------------------- pooling
+def _grad_summary(t):
+    t = t.detach().double().flatten()
+    return np.concatenate([np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()]), t[:: max(1, t.numel() // 509)][:509].numpy()])
+
+
+@pytest.mark.parametrize("tag", ["default", "ape_l2", "default_train"])
+def test_pooling_oracle_matches_reference(golden_dir, tag):
+    """oracle/pooling_oracle.py against outputs and gradients of the reference's Transformer_Module (tests/golden/make_golden_pooling.py)"""
+    from oracle import pooling_oracle as PO
+    fx = np.load(os.path.join(golden_dir, f"pooling_{tag}.npz"))
+    rep, K, d, nhead, L, ff, has_pos, B = [int(v) for v in fx["cfg"]]
+    cfg = PO.default_cfg(rep_dim=rep, num_slots=K, d_model=d, nhead=nhead, num_layers=L, dim_feedforward=ff, pos_emb="ape" if has_pos else "None")
+    P = PO.formula_params(cfg)
+    p_drop = float(fx["p_drop"][0])
+    masks = None
+    if p_drop > 0:
+        S = K + 1
+        shapes = {"drop1": (B, S, d), "ffn": (B, S, ff), "drop2": (B, S, d)}
+        masks = {}
+        for k in fx.files:
+            if k.startswith("m:"):
+                shp = shapes[k.split(".")[-1]]
+                masks[k[2:]] = torch.from_numpy(np.unpackbits(fx[k])[: int(np.prod(shp))].reshape(shp).astype(np.float32))
+    out, g, ds = PO.loss_and_grads(P, torch.from_numpy(fx["slots"]), cfg, torch.from_numpy(fx["cot"]), masks, p_drop)
+    assert np.abs(out.numpy() - fx["out"]).max() < 2e-5 * np.abs(fx["out"]).max()
+    assert np.abs(ds.numpy() - fx["dslots"]).max() < 2e-4 * np.abs(fx["dslots"]).max()
+    gmax = max(np.abs(fx["g:" + n][3:]).max() for n, _ in PO.param_shapes(cfg))
+    for n, _ in PO.param_shapes(cfg):
+        ref, got = fx["g:" + n], _grad_summary(g[n])
+        assert np.abs(got[3:] - ref[3:]).max() < 2e-4 * max(np.abs(ref[3:]).max(), 1e-3 * gmax), n
+        assert abs(got[2] - ref[2]) <= 1e-3 * ref[2] + 1e-12, n
