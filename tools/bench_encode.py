@@ -1,9 +1,15 @@
-"""Latency of the inference path `model(obs)` (SLATE_Module.forward: CNN encoder + slot attention) at RL-style tiny batches."""
+"""Latency of the RL-side inference path at tiny batches (num_envs): `model(obs)` (SLATE_Module.forward: CNN encoder + slot attention)
+and the same followed by the Transformer pooling head (sb3s/ocr_extractor.py:45: pooling(ocr(obs)))."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import slate_config
+import types
 from ocrl_amd import ocrs
+from ocrl_amd.poolings import Transformer_Module
+
+POOL = types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", norm_first=False, use_mlp1=False, use_mlp2=False, cw_embedding=False,
+                             push_embedding=False)
 
 for S in (64, 128):
     ocr, env = slate_config(S)
@@ -12,6 +18,7 @@ for S in (64, 128):
     model._module._max_batch = 32
     model.to("cuda:0")
     model.eval()
+    pool = Transformer_Module(model.rep_dim, model.num_slots, POOL).cuda().eval()
     for B in (1, 8, 32):
         obs = torch.rand(B, 3, S, S, device="cuda")
         for _ in range(5):
@@ -24,3 +31,13 @@ for S in (64, 128):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print(f"encode S={S} B={B}: {dt * 1e3:.3f} ms per call, {B / dt:.0f} images/s", flush=True)
+        with torch.no_grad():
+            for _ in range(5):
+                pool(model(obs))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pool(model(obs))
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"encode + pooling S={S} B={B}: {dt * 1e3:.3f} ms per call", flush=True)
