@@ -18,13 +18,19 @@
 #define TH 4
 #define TW 32
 
+// 3x3 / 64 channels: the tap loop is 2.8x shorter than the 5x5 one, so the halo load and the epilogue weigh more; its halo rows are
+// stored unpadded (64 floats) with the 16-byte chunk index XOR-ed by the pixel index (same bank spread as the +4 padding) so that
+// the tile needs 51 KB instead of 54.2 KB of LDS and THREE workgroups fit a CU to cover each other's load / store phases.
+template <int KS, int CIN> struct ConvCfg { static constexpr bool SWZ = (KS == 3 && CIN == 64); static constexpr int LDH = SWZ ? CIN : CIN + 4, WGS = SWZ ? 3 : 2; };
+
 template <int KS, int CIN, int COUT>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
+__global__ __launch_bounds__(256, (ConvCfg<KS, CIN>::WGS)) void conv_fwd_kernel(ConvArgs p) {
     static_assert(COUT == 64, "COUT must be 64");
     static_assert(CIN % 8 == 0, "CIN must be a multiple of 8");
     constexpr int P = KS / 2;
     constexpr int HW_ = TW + KS - 1, HH_ = TH + KS - 1;
-    constexpr int LDH = CIN + 4;
+    constexpr int LDH = ConvCfg<KS, CIN>::LDH;
+    constexpr bool SWZ = ConvCfg<KS, CIN>::SWZ;
     constexpr int NCH = CIN / 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = threadIdx.x + i * 256;
-            if (idx < TOTAL) *reinterpret_cast<float4*>(smem + (idx / F4) * LDH + (idx % F4) * 4) = hv[i];
+            if (idx < TOTAL) *reinterpret_cast<float4*>(smem + (idx / F4) * LDH + (SWZ ? (((idx % F4) ^ ((idx / F4) & 15)) * 4) : (idx % F4) * 4)) = hv[i];
         }
     }
     __syncthreads();
@@ -74,12 +80,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
         // cycles) ahead of its use, so neither the L2 nor the LDS latency is exposed.
         float4 ra[NCH], rb0[NCH], rb1[NCH];
         {
-            const float* arow = smem + (wave * HW_ + li) * LDH + 4 * lh;
+            const int prow = wave * HW_ + li;
+            const float* arow = smem + prow * LDH + (SWZ ? 0 : 4 * lh);
+            const int sv = (4 * lh) ^ ((prow & 15) * 4);            // swizzled layout: float offset of chunk (2cc + lh) = (8cc) ^ sv
 #pragma unroll
             for (int cc = 0; cc < NCH; ++cc) {
                 rb0[cc] = *reinterpret_cast<const float4*>(wl + (size_t)cc * COUT * 8);
                 rb1[cc] = *reinterpret_cast<const float4*>(wl + (size_t)cc * COUT * 8 + 32 * 8);
-                ra[cc] = *reinterpret_cast<const float4*>(arow + cc * 8);
+                ra[cc] = *reinterpret_cast<const float4*>(arow + (SWZ ? ((cc * 8) ^ sv) : cc * 8));
                 __builtin_amdgcn_sched_barrier(0);      // keep the ring's issue order: the loop's s_waitcnt counts rely on it
             }
         }
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
             const int tn = tap + 1;
             const bool more = tn < KS * KS;
             const int ky = tn / KS, kx = tn - ky * KS;
-            const float* arow = smem + ((wave + (more ? ky : 0)) * HW_ + li + (more ? kx : 0)) * LDH + 4 * lh;
+            const int prow = (wave + (more ? ky : 0)) * HW_ + li + (more ? kx : 0);
+            const float* arow = smem + prow * LDH + (SWZ ? 0 : 4 * lh);
+            const int sv = (4 * lh) ^ ((prow & 15) * 4);
             const float* wn = wl + ((p.diag || !more) ? 0 : (size_t)tn * NCH * COUT * 8);
 #pragma unroll
             for (int cc = 0; cc < NCH; ++cc) {
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvArgs p) {
                 // (after the last tap this harmlessly re-reads tap 0: no branch in the loop body)
                 rb0[cc] = *reinterpret_cast<const float4*>(wn + (size_t)cc * COUT * 8);
                 rb1[cc] = *reinterpret_cast<const float4*>(wn + (size_t)cc * COUT * 8 + 32 * 8);
-                ra[cc] = *reinterpret_cast<const float4*>(arow + cc * 8);
+                ra[cc] = *reinterpret_cast<const float4*>(arow + (SWZ ? ((cc * 8) ^ sv) : cc * 8));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -339,7 +349,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ W, float* __restrict_
 
 template <int KS, int CIN>
 static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
-    constexpr int smem = (TH + KS - 1) * (TW + KS - 1) * (CIN + 4) * 4;
+    constexpr int smem = (TH + KS - 1) * (TW + KS - 1) * ConvCfg<KS, CIN>::LDH * 4;
     static bool attr_set = false;
     if (!attr_set) {
         OCRL_HIP(hipFuncSetAttribute((const void*)conv_fwd_kernel<KS, CIN, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
