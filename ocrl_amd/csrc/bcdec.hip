@@ -179,8 +179,11 @@ __global__ void bc_c4_pack_kernel(const float* __restrict__ W, float* __restrict
 template <int MODE>   // 0: forward (X [.,64] -> Y [.,4]);  1: backward data (dY [.,4] -> dX [.,64], masked by act > 0)
 __global__ __launch_bounds__(128) void bc_c4_conv_kernel(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias,
                                                          const float* __restrict__ act, float* __restrict__ Y, int Bn, int S, int elu) {
+    // MODE 0 stages the 64 input channels in two passes of 32 (LD 36): 29 KB of LDS instead of 55 KB, so five workgroups (10 waves)
+    // share a CU and cover each other's LDS latency -- this kernel is VALU / LDS work with one pixel per thread.
     constexpr int CI = MODE == 0 ? 64 : 4;
-    constexpr int LD = MODE == 0 ? 68 : 4;
+    constexpr int CP = MODE == 0 ? 32 : 4;              // channels per pass
+    constexpr int LD = MODE == 0 ? 36 : 4;
     constexpr int HW_ = BT_W + 2, HH_ = BT_H + 2;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* halo = sm;                                   // [HH_][HW_][LD]
@@ -191,33 +194,49 @@ __global__ __launch_bounds__(128) void bc_c4_conv_kernel(const float* __restrict
     const int ty = bid % tiles_y; bid /= tiles_y;
     const long long b = bid;
     const int x0 = tx * BT_W, y0 = ty * BT_H;
-    {
-        constexpr int F4 = CI / 4;
-        const float* Xb = X + b * S * S * CI;
-        for (int idx = threadIdx.x; idx < HH_ * HW_ * F4; idx += 128) {
+    auto load_halo = [&](int c0) {          // every global load is issued before the first LDS store: one memory round trip per pass
+        constexpr int F4 = CP / 4, TOT = HH_ * HW_ * F4, NLD = (TOT + 127) / 128;
+        const float* Xb = X + b * S * S * CI + c0;
+        float4 hv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 128;
             const int c4 = idx % F4, hp = idx / F4;
             const int x = x0 - 1 + hp % HW_, y = y0 - 1 + hp / HW_;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < S && x >= 0 && x < S) v = *reinterpret_cast<const float4*>(Xb + ((size_t)y * S + x) * CI + c4 * 4);
-            *reinterpret_cast<float4*>(halo + hp * LD + c4 * 4) = v;
+            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOT && y >= 0 && y < S && x >= 0 && x < S) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * S + x) * CI + c4 * 4);
         }
-    }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 128;
+            if (idx < TOT) *reinterpret_cast<float4*>(halo + (idx / F4) * LD + (idx % F4) * 4) = hv[i];
+        }
+    };
+    load_halo(0);
     __syncthreads();
     const int px = threadIdx.x % BT_W, py = threadIdx.x / BT_W;
     const int x = x0 + px, y = y0 + py;
     if (MODE == 0) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CI; c0 += CP) {
+            if (c0) {
+                __syncthreads();
+                load_halo(c0);
+                __syncthreads();
+            }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const float* h = halo + ((py + tap / 3) * HW_ + px + tap % 3) * LD;
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* h = halo + ((py + tap / 3) * HW_ + px + tap % 3) * LD;
 #pragma unroll
-            for (int c4 = 0; c4 < 16; ++c4) {
-                const float4 v = *reinterpret_cast<const float4*>(h + c4 * 4);
-                const float* w = Wt + (tap * 64 + c4 * 4) * 4;      // wave-uniform: scalar loads
-                a0 += v.x * w[0] + v.y * w[4] + v.z * w[8] + v.w * w[12];
-                a1 += v.x * w[1] + v.y * w[5] + v.z * w[9] + v.w * w[13];
-                a2 += v.x * w[2] + v.y * w[6] + v.z * w[10] + v.w * w[14];
-                a3 += v.x * w[3] + v.y * w[7] + v.z * w[11] + v.w * w[15];
+                for (int c4 = 0; c4 < CP / 4; ++c4) {
+                    const float4 v = *reinterpret_cast<const float4*>(h + c4 * 4);
+                    const float* w = Wt + (tap * 64 + c0 + c4 * 4) * 4;      // wave-uniform: scalar loads
+                    a0 += v.x * w[0] + v.y * w[4] + v.z * w[8] + v.w * w[12];
+                    a1 += v.x * w[1] + v.y * w[5] + v.z * w[9] + v.w * w[13];
+                    a2 += v.x * w[2] + v.y * w[6] + v.z * w[10] + v.w * w[14];
+                    a3 += v.x * w[3] + v.y * w[7] + v.z * w[11] + v.w * w[15];
+                }
             }
         }
         if (x < S && y < S)
@@ -274,12 +293,22 @@ __global__ __launch_bounds__(256) void bc_c4_wgrad_kernel(const float* __restric
         const int x0 = tx * BT_W, y0 = ty * BT_H;
         __syncthreads();
         const float* Xb = X + b * S * S * 64;
-        for (int idx = threadIdx.x; idx < HH_ * HW_ * 16; idx += 256) {
-            const int c4 = idx % 16, hp = idx / 16;
-            const int x = x0 - 1 + hp % HW_, y = y0 - 1 + hp / HW_;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y >= 0 && y < S && x >= 0 && x < S) v = *reinterpret_cast<const float4*>(Xb + ((size_t)y * S + x) * 64 + c4 * 4);
-            *reinterpret_cast<float4*>(halo + hp * 64 + c4 * 4) = v;
+        {                                       // all global loads of the tile first, then the LDS stores (one memory round trip per tile)
+            constexpr int TOT = HH_ * HW_ * 16, NLD = (TOT + 255) / 256;
+            float4 hv[NLD];
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = threadIdx.x + i * 256;
+                const int c4 = idx % 16, hp = idx / 16;
+                const int x = x0 - 1 + hp % HW_, y = y0 - 1 + hp / HW_;
+                hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < TOT && y >= 0 && y < S && x >= 0 && x < S) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * S + x) * 64 + c4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int idx = threadIdx.x + i * 256;
+                if (idx < TOT) *reinterpret_cast<float4*>(halo + (idx / 16) * 64 + (idx % 16) * 4) = hv[i];
+            }
         }
         if (threadIdx.x < BT_H * BT_W) {
             const int x = x0 + threadIdx.x % BT_W, y = y0 + threadIdx.x / BT_W;
@@ -288,7 +317,8 @@ __global__ __launch_bounds__(256) void bc_c4_wgrad_kernel(const float* __restric
             *reinterpret_cast<float4*>(ds + threadIdx.x * 4) = v;
         }
         __syncthreads();
-        for (int p = 0; p < BT_H * BT_W; ++p) {
+#pragma unroll 8
+        for (int p = 0; p < BT_H * BT_W; ++p) {          // unrolled: eight pixels' LDS reads in flight per thread
             const float4 d = *reinterpret_cast<const float4*>(ds + p * 4);
             const int px = p % BT_W, py = p / BT_W;
 #pragma unroll
@@ -395,7 +425,7 @@ int bc_c4_pack_launch(const float* W, float* Wk, float* Wb, int co_n, hipStream_
 }
 int bc_c4_fwd_launch(const float* X, const float* Wk, const float* bias4, float* Y, int Bn, int S, hipStream_t st) {
     const int grid = cdiv(S, BT_W) * cdiv(S, BT_H) * Bn;
-    const int smem = (BT_H + 2) * (BT_W + 2) * 68 * 4;
+    const int smem = (BT_H + 2) * (BT_W + 2) * 36 * 4;
     static bool set = false;
     if (!set) { OCRL_HIP(hipFuncSetAttribute((const void*)bc_c4_conv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); set = true; }
     hipLaunchKernelGGL((bc_c4_conv_kernel<0>), dim3(grid), dim3(128), smem, st, X, Wk, bias4, nullptr, Y, Bn, S, 0);
