@@ -21,7 +21,9 @@ def shapes(D, H):
     return [(C,), (C,), (D,), (D,), (D,), (D,), (D, D), (D, C), (D, C), (3 * D, D), (3 * D, D), (3 * D,), (3 * D,), (H, D), (H,), (D, H), (D,)]
 
 
-@pytest.mark.parametrize("B,N,K,D,H,I", [(3, 200, 5, 128, 192, 3), (2, 1024, 6, 192, 192, 3), (2, 77, 16, 64, 64, 2), (1, 16, 1, 256, 256, 1), (2, 300, 11, 192, 128, 2)])
+# the last four shapes take the split forward (several workgroups per image, one launch per iteration): 4, 8, 16 and 8 workgroups per image
+@pytest.mark.parametrize("B,N,K,D,H,I", [(3, 200, 5, 128, 192, 3), (2, 1024, 6, 192, 192, 3), (2, 77, 16, 64, 64, 2), (1, 16, 1, 256, 256, 1), (2, 300, 11, 192, 128, 2),
+                                         (3, 2100, 6, 192, 192, 3), (2, 4099, 16, 64, 64, 2), (2, 8200, 11, 192, 128, 2), (1, 4096, 1, 128, 64, 3)])
 def test_slot_attention_unit(B, N, K, D, H, I):
     from ocrl_amd import _lib
     L = _lib.lib()
