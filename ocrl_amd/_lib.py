@@ -4,7 +4,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocrl_hip.so")
+LIB_PATH = os.environ.get("OCRL_HIP_LIB") or os.path.join(_HERE, "libocrl_hip.so")      # OCRL_HIP_LIB: development builds
 _lib = None
 
 

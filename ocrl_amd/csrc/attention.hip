@@ -14,6 +14,9 @@
 #include "kernels.h"
 
 #define FA_BLK 64
+#ifndef FA_BWD_WGS
+#define FA_BWD_WGS 3      // workgroups per CU the backward kernels are compiled for (register budget 512 / FA_BWD_WGS per lane)
+#endif
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -37,6 +40,30 @@ __device__ inline void fa_load_tile(float* s, const float* __restrict__ g, long 
     }
 }
 
+// Register-staged variant: fa_fetch issues the global loads of a tile into registers, fa_commit writes them to LDS one iteration
+// later, so the memory round trip of tile t+1 overlaps the MFMA work on tile t instead of sitting between two barriers.
+template <int DH> struct FaRegs { static constexpr int N = (FA_BLK * (DH / 4) + 255) / 256; };
+template <int DH>
+__device__ inline void fa_fetch(float4 (&r)[FaRegs<DH>::N], const float* __restrict__ g, long long bt0, int row0, int T, int d, int hoff) {
+    constexpr int F4 = DH / 4;
+#pragma unroll
+    for (int i = 0; i < FaRegs<DH>::N; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int c4 = idx % F4, row = idx / F4;
+        r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < FA_BLK * F4 && row0 + row < T) r[i] = *reinterpret_cast<const float4*>(g + (bt0 + row0 + row) * d + hoff + c4 * 4);
+    }
+}
+template <int DH>
+__device__ inline void fa_commit(float* s, const float4 (&r)[FaRegs<DH>::N], float scale) {
+    constexpr int F4 = DH / 4, LD = FaCfg<DH>::LD;
+#pragma unroll
+    for (int i = 0; i < FaRegs<DH>::N; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < FA_BLK * F4) *reinterpret_cast<float4*>(s + (idx / F4) * LD + (idx % F4) * 4) = make_float4(r[i].x * scale, r[i].y * scale, r[i].z * scale, r[i].w * scale);
+    }
+}
+
 // Blocks are dealt round-robin over the 8 XCDs, and causal work per block grows with its index: a fixed
 // blockIdx -> block-index map gives each XCD always the same (heavy or light) classes — measured 2.4x imbalance,
 // CUs 67 % busy.  Rotating the block index by the (batch, head) index hands every XCD a uniform mix.
@@ -49,7 +76,7 @@ __device__ inline int fa_block_index(int j, long long bh, int nblk) {
 
 // ------------------------------------------------------------------------------------------- forward
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(AttnArgs p) {
     constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD;
     __shared__ __attribute__((aligned(16))) float Ks[FA_BLK * LD];
     __shared__ __attribute__((aligned(16))) float Vs[FA_BLK * LD];
@@ -81,11 +108,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const uint32_t thr = drop_thresh(p.p);
     const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
 
+    float4 rk[FaRegs<DH>::N], rv[FaRegs<DH>::N];
+    fa_fetch<DH>(rk, p.k, bt0, 0, T, d, hoff);
+    fa_fetch<DH>(rv, p.v, bt0, 0, T, d, hoff);
     for (int kt = 0; kt <= qb; ++kt) {
         __syncthreads();
-        fa_load_tile<DH>(Ks, p.k, bt0, kt * FA_BLK, T, d, hoff, 1.f);
-        fa_load_tile<DH>(Vs, p.v, bt0, kt * FA_BLK, T, d, hoff, 1.f);
+        fa_commit<DH>(Ks, rk, 1.f);
+        fa_commit<DH>(Vs, rv, 1.f);
         __syncthreads();
+        if (kt < qb) {                                         // next tile in flight during this tile's MFMAs
+            fa_fetch<DH>(rk, p.k, bt0, (kt + 1) * FA_BLK, T, d, hoff);
+            fa_fetch<DH>(rv, p.v, bt0, (kt + 1) * FA_BLK, T, d, hoff);
+        }
         f32x4_t s[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) s[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------- backward: dK, dV
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_kv_kernel(AttnArgs p) {
     constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD;
     __shared__ __attribute__((aligned(16))) float Qs[FA_BLK * LD];
     __shared__ __attribute__((aligned(16))) float Gs[FA_BLK * LD];      // dO
@@ -229,16 +263,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
     const uint32_t thr = drop_thresh(p.p);
     const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
 
-    for (int qt = kb; qt < nkb; ++qt) {
-        __syncthreads();
-        fa_load_tile<DH>(Qs, p.q, bt0, qt * FA_BLK, T, d, hoff, scale);
-        fa_load_tile<DH>(Gs, p.dO, bt0, qt * FA_BLK, T, p.d, hoff, 1.f);
+    float4 rq[FaRegs<DH>::N], rg[FaRegs<DH>::N];
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int qt) {
+        fa_fetch<DH>(rq, p.q, bt0, qt * FA_BLK, T, d, hoff);
+        fa_fetch<DH>(rg, p.dO, bt0, qt * FA_BLK, T, p.d, hoff);
         if (threadIdx.x < FA_BLK) {
             const int qq = qt * FA_BLK + threadIdx.x;
-            Ls[threadIdx.x] = qq < T ? p.lse[bh * T + qq] : 0.f;
-            Ds[threadIdx.x] = qq < T ? p.delta[bh * T + qq] : 0.f;
+            rl = qq < T ? p.lse[bh * T + qq] : 0.f;
+            rd = qq < T ? p.delta[bh * T + qq] : 0.f;
         }
+    };
+    fetch(kb);
+    for (int qt = kb; qt < nkb; ++qt) {
         __syncthreads();
+        fa_commit<DH>(Qs, rq, scale);
+        fa_commit<DH>(Gs, rg, 1.f);
+        if (threadIdx.x < FA_BLK) { Ls[threadIdx.x] = rl; Ds[threadIdx.x] = rd; }
+        __syncthreads();
+        if (qt + 1 < nkb) fetch(qt + 1);
 #pragma unroll
         for (int sq = 0; sq < 4; ++sq) {
             f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
@@ -303,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------- backward: dQ
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_q_kernel(AttnArgs p) {
     constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD;
     __shared__ __attribute__((aligned(16))) float Ks[FA_BLK * LD];
     __shared__ __attribute__((aligned(16))) float Vs[FA_BLK * LD];
@@ -340,11 +383,18 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs p) {
     const uint32_t thr = drop_thresh(p.p);
     const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
 
+    float4 rk[FaRegs<DH>::N], rv[FaRegs<DH>::N];
+    fa_fetch<DH>(rk, p.k, bt0, 0, T, d, hoff);
+    fa_fetch<DH>(rv, p.v, bt0, 0, T, d, hoff);
     for (int kt = 0; kt <= qb; ++kt) {
         __syncthreads();
-        fa_load_tile<DH>(Ks, p.k, bt0, kt * FA_BLK, T, d, hoff, 1.f);
-        fa_load_tile<DH>(Vs, p.v, bt0, kt * FA_BLK, T, d, hoff, 1.f);
+        fa_commit<DH>(Ks, rk, 1.f);
+        fa_commit<DH>(Vs, rv, 1.f);
         __syncthreads();
+        if (kt < qb) {
+            fa_fetch<DH>(rk, p.k, bt0, (kt + 1) * FA_BLK, T, d, hoff);
+            fa_fetch<DH>(rv, p.v, bt0, (kt + 1) * FA_BLK, T, d, hoff);
+        }
         f32x4_t sS[4], sP[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) { sS[st] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; sP[st] = sS[st]; }
