@@ -14,6 +14,9 @@
 #include "kernels.h"
 
 #define FA_BLK 64
+#ifndef FA_LPT
+#define FA_LPT 1          // 1: longest-first block order; 0: (image, head)-major order with the block index rotated per pair
+#endif
 #ifndef FA_BWD_WGS
 #define FA_BWD_WGS 3      // workgroups per CU the backward kernels are compiled for (register budget 512 / FA_BWD_WGS per lane)
 #endif
@@ -81,9 +84,14 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) float Ks[FA_BLK * LD];
     __shared__ __attribute__((aligned(16))) float Vs[FA_BLK * LD];
     const int nqb = (p.T + FA_BLK - 1) / FA_BLK;
+    // longest-first dispatch: blockIdx runs over the tile-count classes from the heaviest (last query block: nqb key tiles) to the
+    // lightest, all (image, head) pairs of a class together, so the launch ends on one-tile blocks instead of on a 16-tile block
+    // that started late (with the rotated (image, head)-major order a third of the wave slots sat empty: SQ_WAVE_CYCLES).
+    // Every class has B*h blocks dealt round-robin to the XCDs, so each XCD still gets the same mix.
     int bid = blockIdx.x;
-    const int jq = bid % nqb; bid /= nqb;
-    const int qb = fa_block_index(jq, bid, nqb);
+    const int nbh = gridDim.x / nqb;
+    const int qb = FA_LPT ? nqb - 1 - bid / nbh : fa_block_index(bid % nqb, bid / nqb, nqb);
+    bid = FA_LPT ? bid % nbh : bid / nqb;
     const int hd = bid % p.h;
     const long long b = bid / p.h;
     const int T = p.T, d = p.ld, hoff = hd * DH;
@@ -180,15 +188,28 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(AttnArgs p) {
                 for (int r = 0; r < 4; ++r) s[st][r] = rng_keep(bits, r, thr) ? s[st][r] * dsc : 0.f;
             }
         }
+        // V^T operands of sub-tile st + 1 are read from LDS before the 4 * NC MFMAs of sub-tile st are issued (ping-pong registers;
+        // the scheduling barriers keep that order), so the LDS latency sits under a sub-tile's worth of matrix work
+        float av[2][4][NC];
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) av[0][r][c] = Vs[(4 * g + r) * LD + 16 * c + li];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (st + 1 < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) av[(st + 1) & 1][r][c] = Vs[(16 * (st + 1) + 4 * g + r) * LD + 16 * c + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {          // NC independent chains per step
-                    const float a = Vs[(16 * st + 4 * g + r) * LD + 16 * c + li];
-                    o[c] = MFMA16(a, s[st][r], o[c]);
-                }
+                for (int c = 0; c < NC; ++c) o[c] = MFMA16(av[st & 1][r][c], s[st][r], o[c]);          // NC independent chains per step
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (q_abs < T) {
         const float inv = 1.0f / l;
@@ -234,9 +255,10 @@ __global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_kv_kernel(AttnArgs p
     __shared__ __attribute__((aligned(16))) float Gs[FA_BLK * LD];      // dO
     __shared__ float Ls[FA_BLK], Ds[FA_BLK];
     const int nkb = (p.T + FA_BLK - 1) / FA_BLK;
-    int bid = blockIdx.x;
-    const int jk = bid % nkb; bid /= nkb;
-    const int kb = fa_block_index(jk, bid, nkb);
+    int bid = blockIdx.x;                                   // longest first: key block 0 meets every query tile
+    const int nbh = gridDim.x / nkb;
+    const int kb = FA_LPT ? bid / nbh : fa_block_index(bid % nkb, bid / nkb, nkb);
+    bid = FA_LPT ? bid % nbh : bid / nkb;
     const int hd = bid % p.h;
     const long long b = bid / p.h;
     const int T = p.T, d = p.ld, hoff = hd * DH;
@@ -324,14 +346,22 @@ __global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_kv_kernel(AttnArgs p
                 pd[r] = pr * keep;
                 ds[r] = pr * (dp[r] * keep - Ds[ql]);
             }
+            // all 8 * NC transposed operands of the sub-tile are requested first, then the 8 * NC MFMAs run (2 * NC independent chains)
+            float ag[4][NC], aq[4][NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ag = Gs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
-                    dv[c] = MFMA16(ag, pd[r], dv[c]);
-                    const float aq = Qs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
-                    dk[c] = MFMA16(aq, ds[r], dk[c]);
+                for (int c = 0; c < NC; ++c) {
+                    ag[r][c] = Gs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
+                    aq[r][c] = Qs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    dv[c] = MFMA16(ag[r][c], pd[r], dv[c]);
+                    dk[c] = MFMA16(aq[r][c], ds[r], dk[c]);
                 }
         }
     }
@@ -351,9 +381,14 @@ __global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_q_kernel(AttnArgs p)
     __shared__ __attribute__((aligned(16))) float Ks[FA_BLK * LD];
     __shared__ __attribute__((aligned(16))) float Vs[FA_BLK * LD];
     const int nqb = (p.T + FA_BLK - 1) / FA_BLK;
+    // longest-first dispatch: blockIdx runs over the tile-count classes from the heaviest (last query block: nqb key tiles) to the
+    // lightest, all (image, head) pairs of a class together, so the launch ends on one-tile blocks instead of on a 16-tile block
+    // that started late (with the rotated (image, head)-major order a third of the wave slots sat empty: SQ_WAVE_CYCLES).
+    // Every class has B*h blocks dealt round-robin to the XCDs, so each XCD still gets the same mix.
     int bid = blockIdx.x;
-    const int jq = bid % nqb; bid /= nqb;
-    const int qb = fa_block_index(jq, bid, nqb);
+    const int nbh = gridDim.x / nqb;
+    const int qb = FA_LPT ? nqb - 1 - bid / nbh : fa_block_index(bid % nqb, bid / nqb, nqb);
+    bid = FA_LPT ? bid % nbh : bid / nqb;
     const int hd = bid % p.h;
     const long long b = bid / p.h;
     const int T = p.T, d = p.ld, hoff = hd * DH;
@@ -432,15 +467,26 @@ __global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_q_kernel(AttnArgs p)
                 sS[st][r] = pr * (sP[st][r] * keep - dlt);          // dS^T
             }
         }
+        float ak[2][4][NC];                              // K^T operands one sub-tile ahead of their MFMAs (see the forward kernel)
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ak[0][r][c] = Ks[(4 * g + r) * LD + 16 * c + li];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (st + 1 < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) ak[(st + 1) & 1][r][c] = Ks[(16 * (st + 1) + 4 * g + r) * LD + 16 * c + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const float a = Ks[(16 * st + 4 * g + r) * LD + 16 * c + li];
-                    dq[c] = MFMA16(a, sS[st][r], dq[c]);
-                }
+                for (int c = 0; c < NC; ++c) dq[c] = MFMA16(ak[st & 1][r][c], sS[st][r], dq[c]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (q_abs < T) {
 #pragma unroll
