@@ -132,7 +132,7 @@ void SlateModel::layout_workspace(bool commit) {
     scratch_floats_ = 0;
     {
         size_t need = conv_wgrad_ws_floats((int)(B * (cfg.use_bcdec ? K : 1)), S, S, 5, 64) + (size_t)512 * 2304 * 2;
-        size_t sk = (size_t)16 * V * d + (size_t)(1 << 20);        // split-k slabs for the [V,d] weights
+        size_t sk = (size_t)32 * V * d + (size_t)(1 << 20);        // split-k slabs ([V,d] weights x16; 170 slabs of the [4d,d] FFN weights)
         if (sk > need) need = sk;
         size_t cs = (size_t)N * C * 8 + (size_t)T * d * 8 + (1 << 20);   // column-sum partials (pos map / pe)
         if (cs > need) need = cs;
@@ -313,7 +313,10 @@ int SlateModel::lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, f
     a.A = dy; a.B = x; a.C = dW; a.M = N_out; a.N = K_in; a.K = (int)M; a.lda = ld_dy; a.ldb = ldx; a.ldc = K_in; a.akc = 0; a.bkc = 0;
     a.alpha = alpha;
     if (dr.p > 0.f) { a.adrop_p = dr.p; a.adrop_site = dr.site; a.adrop_ld = N_out; a.drop_seed = last_.seed; }
-    const int tiles = cdiv(N_out, 128) * cdiv(K_in, (K_in % 128 == 0) ? 128 : 64);
+    // output tiles as gemm.hip will cut them (128x192 for 192 input features over >= 4096 rows, else 128x128 / 128x64): the split count
+    // aims at ~1024 workgroups -- counting 64-wide tiles for the 128x192 case left 340 workgroups on 256 CUs (PMC: 0.95 waves per SIMD)
+    const int col_tiles = (K_in == 192 && M >= 4096) ? 1 : cdiv(K_in, (K_in % 128 == 0) ? 128 : 64);
+    const int tiles = cdiv(N_out, 128) * col_tiles;
     long long splits = 1024 / tiles;
     if (splits > M / 256) splits = M / 256;
     if (splits < 1) splits = 1;
