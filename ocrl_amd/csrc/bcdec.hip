@@ -255,16 +255,28 @@ __global__ __launch_bounds__(128) void bc_c4_conv_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < 64; ++c) stage[threadIdx.x * 65 + c] = acc[c];
         __syncthreads();
-        // coalesced store of the 4x32 tile: 16 float4 per pixel
-        for (int idx = threadIdx.x; idx < BT_H * BT_W * 16; idx += 128) {
+        // coalesced store of the 4x32 tile: 16 float4 per pixel; the 16 activation reads of a thread are issued together
+        constexpr int NST = BT_H * BT_W * 16 / 128;
+        float4 mv[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = threadIdx.x + i * 128;
+            const int c4 = idx % 16, p = idx / 16;
+            const int xx = x0 + p % BT_W, yy = y0 + p / BT_W;
+            mv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (xx < S && yy < S) mv[i] = *reinterpret_cast<const float4*>(act + ((b * S + yy) * S + xx) * 64 + c4 * 4);
+        }
+        const float e = elu ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int idx = threadIdx.x + i * 128;
             const int c4 = idx % 16, p = idx / 16;
             const int xx = x0 + p % BT_W, yy = y0 + p / BT_W;
             if (xx >= S || yy >= S) continue;
             const size_t o = ((b * S + yy) * S + xx) * 64 + c4 * 4;
-            const float4 m = *reinterpret_cast<const float4*>(act + o);
+            const float4 m = mv[i];
             const float* sp = stage + p * 65 + c4 * 4;
             // gate by the derivative of the saved activation: ReLU' (m > 0) or ELU' (m > 0 ? 1 : m + 1)
-            const float e = elu ? 1.f : 0.f;
             *reinterpret_cast<float4*>(Y + o) = make_float4(m.x > 0.f ? sp[0] : e * (m.x + 1.f) * sp[0], m.y > 0.f ? sp[1] : e * (m.y + 1.f) * sp[1],
                                                             m.z > 0.f ? sp[2] : e * (m.z + 1.f) * sp[2], m.w > 0.f ? sp[3] : e * (m.w + 1.f) * sp[3]);
         }
@@ -285,38 +297,41 @@ __global__ __launch_bounds__(256) void bc_c4_wgrad_kernel(const float* __restric
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // the next tile's halo (13 float4 per thread) and dY are fetched into registers while the current tile is being reduced
+    constexpr int TOT = HH_ * HW_ * 16, NLD = (TOT + 255) / 256;
+    float4 hv[NLD], dv;
+    auto fetch = [&](int t) {
         int q = t;
         const int tx = q % tiles_x; q /= tiles_x;
         const int ty = q % tiles_y; q /= tiles_y;
         const long long b = q;
         const int x0 = tx * BT_W, y0 = ty * BT_H;
-        __syncthreads();
         const float* Xb = X + b * S * S * 64;
-        {                                       // all global loads of the tile first, then the LDS stores (one memory round trip per tile)
-            constexpr int TOT = HH_ * HW_ * 16, NLD = (TOT + 255) / 256;
-            float4 hv[NLD];
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int idx = threadIdx.x + i * 256;
-                const int c4 = idx % 16, hp = idx / 16;
-                const int x = x0 - 1 + hp % HW_, y = y0 - 1 + hp / HW_;
-                hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < TOT && y >= 0 && y < S && x >= 0 && x < S) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * S + x) * 64 + c4 * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int idx = threadIdx.x + i * 256;
-                if (idx < TOT) *reinterpret_cast<float4*>(halo + (idx / 16) * 64 + (idx % 16) * 4) = hv[i];
-            }
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int c4 = idx % 16, hp = idx / 16;
+            const int x = x0 - 1 + hp % HW_, y = y0 - 1 + hp / HW_;
+            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOT && y >= 0 && y < S && x >= 0 && x < S) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * S + x) * 64 + c4 * 4);
         }
+        dv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (threadIdx.x < BT_H * BT_W) {
             const int x = x0 + threadIdx.x % BT_W, y = y0 + threadIdx.x / BT_W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (x < S && y < S) v = *reinterpret_cast<const float4*>(dY + ((b * S + y) * S + x) * 4);
-            *reinterpret_cast<float4*>(ds + threadIdx.x * 4) = v;
+            if (x < S && y < S) dv = *reinterpret_cast<const float4*>(dY + ((b * S + y) * S + x) * 4);
         }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            if (idx < TOT) *reinterpret_cast<float4*>(halo + (idx / 16) * 64 + (idx % 16) * 4) = hv[i];
+        }
+        if (threadIdx.x < BT_H * BT_W) *reinterpret_cast<float4*>(ds + threadIdx.x * 4) = dv;
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
 #pragma unroll 8
         for (int p = 0; p < BT_H * BT_W; ++p) {          // unrolled: eight pixels' LDS reads in flight per thread
             const float4 d = *reinterpret_cast<const float4*>(ds + p * 4);
