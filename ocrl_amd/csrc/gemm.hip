@@ -357,11 +357,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const long long i = (long long)blockIdx.x * 16 + cl;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n4)
-        for (int k = sl; k < splits; k += 16) {
+    if (i < n4) {
+        int k = sl;
+        for (; k + 48 < splits; k += 64) {          // four slabs in flight per thread
+            const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)k * stride + i * 4);
+            const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(k + 16) * stride + i * 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(k + 32) * stride + i * 4);
+            const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(k + 48) * stride + i * 4);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; k < splits; k += 16) {
             const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * stride + i * 4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     red[sl][cl] = s;
     __syncthreads();
     if (sl == 0 && i < n4) {
