@@ -231,10 +231,13 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     named_.clear();
     layout_workspace(true);
     if (!side_) {
-        // OCRL_OVERLAP=1: +2.7 % images/s at config A, but kernels of the two branches then share the GPU and per-kernel timings
-        // (bench.py's roofline line, rocprofv3 durations) stop being comparable; off by default
+        // OCRL_OVERLAP (default 2): 2 = the dVAE branch is forked onto a side stream only at the slot-attention launches (one workgroup
+        // per image: half the CUs idle at B=128) and joined before the next 5x5 convolution, so the roofline kernel never shares the GPU
+        // (+1.8 % images/s, conv timings unchanged); 1 = whole dVAE branch beside encoder + decoder (+0.8 %, but per-kernel timings of
+        // both branches stop being comparable); 0 = single stream
         const char* e = getenv("OCRL_OVERLAP");
-        if (e && atoi(e)) {
+        overlap_mode_ = e ? atoi(e) : 2;
+        if (overlap_mode_) {
             OCRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
             OCRL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
             OCRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
@@ -373,7 +376,7 @@ int SlateModel::pack_weights(hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // CNN encoder + slot attention (ocrs/common/models.py:96-107, slot_attn.py:147-161)
-int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st) {
+int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, bool fork_dvae) {
     const int B = in.B;
     const long long BN = (long long)B * N;
     RC(nchw_to_nhwc8_launch(in.obs, obs8_, B, cfg.obs_channels, S, S, st));
@@ -389,6 +392,14 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st) {
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
     a.xchg = sa_xchg_; a.counters = sa_counters_;
+    if (fork_dvae) {
+        RC(fork_side(st));
+        std::swap(scratch_, scratch2_);
+        const int rc = fwd_dvae(in, side_);
+        std::swap(scratch_, scratch2_);
+        RC(rc);
+        a.xchg = nullptr; a.counters = nullptr;      // fused one-workgroup-per-image kernel: the dVAE kernels take the other CUs
+    }
     RC(slot_attn_launch(a, 0, st));
     return 0;
 }
@@ -491,7 +502,10 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
     }
     // the dVAE branch (tokens, reconstruction loss) and the CNN encoder + slot attention are independent until the decoder:
     // the dVAE runs on the side stream, filling the CUs the one-workgroup-per-image slot-attention kernel leaves idle
-    if (side_) {
+    if (side_ && overlap_mode_ == 2) {
+        RC(fwd_encoder(in, st, true));       // forks the dVAE forward right before the slot-attention launch
+        RC(join_side(st));
+    } else if (side_) {
         RC(fork_side(st));
         std::swap(scratch_, scratch2_);
         const int rc = fwd_dvae(in, side_);
@@ -619,7 +633,7 @@ int SlateModel::bwd_decoder(hipStream_t st) {
     return 0;
 }
 
-int SlateModel::bwd_encoder(hipStream_t st) {
+int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
     const int B = last_.B;
     const long long BN = (long long)B * N, R = (long long)B * I * K;
     const SaSave so = sa_save_layout(C, D, H);
@@ -628,6 +642,13 @@ int SlateModel::bwd_encoder(hipStream_t st) {
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.wts = sa_wts_; a.save = sa_save_; a.dslots = gslots_; a.dx = gA_; a.dslots0 = gslots0_; a.grows = sa_grows_; a.g_small = sa_small_;
+    if (fork_dvae) {
+        RC(fork_side(st));
+        std::swap(scratch_, scratch2_);
+        const int rc = bwd_dvae(side_);
+        std::swap(scratch_, scratch2_);
+        RC(rc);
+    }
     RC(slot_attn_launch(a, 1, st));
     // weight gradients: contract the emitted gradient rows with the saved activations over (image, iteration, slot)
     RC(lin_bwd_w(sa_grows_ + go.out, go.ld, sa_save_ + so.hid, so.ld, G(sa + "mlp.2.weight"), G(sa + "mlp.2.bias"), R, D, H, 1.f, st));
@@ -653,6 +674,7 @@ int SlateModel::bwd_encoder(hipStream_t st) {
     // ---- positional embedding (added to every image): d map = sum over images
     RC(colsum_launch(gB_, (long long)N * C, gmap_, B, N * C, 0, 1.f, scratch_, scratch_floats_, st));
     RC(lin_bwd_w(gmap_, C, gridT_, 4, G("_enc_pos.channels_map.weight"), G("_enc_pos.channels_map.bias"), N, C, 4, 1.f, st));
+    if (fork_dvae) RC(join_side(st));
     // ---- CNN encoder, last layer first
     RC(conv_layer_wgrad(e3_, gB_, G("_enc._encoder.3.weight"), G("_enc._encoder.3.bias"), B, S, S, 5, 64, 64, st));
     RC(conv_layer_fwd(gB_, cw_bwd_[3], nullptr, gA_, B, S, S, 5, 64, 0, nullptr, e3_, st));                       // gA = d e3 (pre-relu)
@@ -737,7 +759,10 @@ int SlateModel::backward(hipStream_t st) {
         have_fwd_ = false;
         return 0;
     }
-    if (side_) {         // the dVAE backward only needs the forward's reconstruction gradient: it overlaps decoder + encoder
+    if (side_ && overlap_mode_ == 2) {
+        RC(bwd_decoder(st));
+        RC(bwd_encoder(st, true));           // forks the dVAE backward at the slot-attention launch, joins before the 5x5 convolutions
+    } else if (side_) {         // the dVAE backward only needs the forward's reconstruction gradient: it overlaps decoder + encoder
         RC(fork_side(st));
         std::swap(scratch_, scratch2_);
         const int rc = bwd_dvae(side_);

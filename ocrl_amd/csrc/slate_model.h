@@ -78,12 +78,12 @@ private:
     int conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN, int cin_real,
                          hipStream_t st);
     int pack_weights(hipStream_t st);
-    int fwd_encoder(const StepInputs& in, hipStream_t st);
+    int fwd_encoder(const StepInputs& in, hipStream_t st, bool fork_dvae = false);
     int fwd_dvae(const StepInputs& in, hipStream_t st);
     int fwd_decoder(hipStream_t st, bool with_ce = true);
     int dvae_decode(int B, float* drecon, hipStream_t st, const float* zin = nullptr);
     int bwd_decoder(hipStream_t st);
-    int bwd_encoder(hipStream_t st);
+    int bwd_encoder(hipStream_t st, bool fork_dvae = false);
     int bwd_dvae(hipStream_t st);
     int pack_bcdec(hipStream_t st);
     int fwd_bcdec(hipStream_t st);
@@ -111,6 +111,7 @@ private:
     float *scratch_ = nullptr;            // transient: split-k slabs, column-sum partials, wgrad slabs
     size_t scratch_floats_ = 0;
     float* scratch2_ = nullptr;           // scratch of the dVAE branch when it runs on the side stream
+    int overlap_mode_ = 0;                // OCRL_OVERLAP: 0 off, 1 whole dVAE branch beside encoder + decoder, 2 dVAE beside the slot-attention kernels only
     hipStream_t side_ = nullptr;          // dVAE forward / backward overlap the encoder + decoder work (independent branches)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     int fork_side(hipStream_t st);
