@@ -101,3 +101,27 @@ def test_schedules_match_oracle():
     for step in (0, 1, 999, 15000, 29999, 30000, 50000):
         assert cosine_anneal(step, 1.0, 0.1, 0, 30000) == O.cosine_anneal(step, 1.0, 0.1, 0, 30000)
         assert linear_warmup(step, 0, 1, 0, 30000) == O.linear_warmup(step, 0, 1, 0, 30000)
+
+
+def test_pooling_module_mirrors_reference_state_dict():
+    """poolings.Transformer_Module holds its parameters under the reference's names / shapes (checkpoints load unchanged) and refuses a
+    CPU tensor instead of falling back (no compute here)."""
+    import types
+    import torch
+    from oracle import pooling_oracle as PO
+    from ocrl_amd.poolings import Transformer_Module
+    for over, pos in ((dict(), "None"), (dict(num_layers=2, nhead=4, num_slots=4, rep_dim=64), "ape")):
+        cfg = PO.default_cfg(pos_emb=pos, **over)
+        pc = types.SimpleNamespace(d_model=cfg.d_model, nhead=cfg.nhead, num_layers=cfg.num_layers, pos_emb=pos, norm_first=False, use_mlp1=False,
+                                   use_mlp2=False, cw_embedding=False, push_embedding=False)
+        m = Transformer_Module(cfg.rep_dim, cfg.num_slots, pc)
+        sd = m.state_dict()
+        names = [(n, tuple(s)) for n, s in PO.param_shapes(cfg)]
+        assert [(k, tuple(v.shape)) for k, v in sd.items() if not k.endswith(".pe")] == names
+        if pos == "ape":
+            assert tuple(sd["_trans._pos.pe"].shape) == (cfg.num_slots + 1, 1, cfg.d_model)
+            assert torch.allclose(sd["_trans._pos.pe"][:, 0], PO.pos_table(cfg))
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(2, cfg.num_slots, cfg.rep_dim))
+    with pytest.raises(NotImplementedError):
+        Transformer_Module(64, 4, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", use_mlp1=True))
