@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
 FWD_FLOP_PER_IMAGE = {(128, 6): 22384148480, (64, 6): 5004001280, (256, 16): 129805844480}     # (S, slots), 3 iters
 
 
@@ -37,32 +38,115 @@ def slate_config(obs_size, num_slots=6, num_iterations=3):
     return ocr, env
 
 
-def cpu_baseline(obs_size, batch, steps):
-    """the CPU oracle's update() (port of ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74) on the host cores"""
-    from oracle import slate_oracle as O
-    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+def _host_cores():
     try:
         cores = len(os.sched_getaffinity(0))      # the cores this process may actually use (not the host's total)
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    return max(1, min(cores, 64))
+
+
+def cpu_baseline(obs_size, batch, steps, use_bcdec=False):
+    """the CPU oracle's update() (port of ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74) on the host cores: SURVEY.md §8(d) —
+    batch 8, train mode dropout 0.1, 1 warm-up + >= 3 timed steps, median"""
+    from oracle import slate_oracle as O
+    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+    cores = _host_cores()
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: oracle update() on {cores} host threads, batch {batch}, {steps} timed steps", file=sys.stderr, flush=True)
-    cfg = O.default_cfg(obs_size=obs_size, num_slots=6, num_iterations=3)
+    cfg = O.default_cfg(obs_size=obs_size, num_slots=6, num_iterations=3, use_bcdec=use_bcdec)
     tr = O.OracleTrainer(cfg, O.formula_params(cfg))
     obs = scenes_to_obs(random_sprite_scenes(batch, obs_size, seed=123))
     times = []
     for step in range(steps + 1):
         t0 = time.perf_counter()
         noise = O.make_noise(cfg, batch, step)           # the reference draws these inside the step (RNG-bound on CPU)
-        masks = O.make_masks(cfg, batch, 1000 + step)
+        masks = None if use_bcdec else O.make_masks(cfg, batch, 1000 + step)
         tr.update(obs, noise, step, masks)
         times.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline step {step}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
-    t = sum(times[1:]) / steps
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    name = "Slot-Attention (use_bcdec)" if use_bcdec else "SLATE"
     return {"value": round(batch / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle update() SLATE {obs_size}x{obs_size}/6 slots/3 iters, batch {batch}, train mode dropout 0.1, "
-                      f"1 warm-up + {steps} timed steps, {t:.2f} s/step"}
+            "sample": f"oracle update() {name} {obs_size}x{obs_size}/6 slots/3 iters, batch {batch}, train mode dropout 0.1, "
+                      f"1 warm-up + {steps} timed steps, median {t:.2f} s/step (an un-tuned PyTorch-CPU port of the reference step; the reference "
+                      f"modules themselves measured 1.33 images/s on 8 threads for SLATE 128x128, SURVEY.md §6)"}
+
+
+def cpu_baseline_iodine(obs_size, num_slots, batch, steps):
+    """oracle/iodine_oracle.py (port of ocrs/iodine/iodine_module.py:79-252 + ocrs/base.py:60-74) on the host cores"""
+    from oracle import iodine_oracle as IO
+    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    cfg = IO.default_cfg(obs_size=obs_size, num_slots=num_slots)
+    tr = IO.OracleTrainer(cfg, IO.formula_params(cfg))
+    obs = scenes_to_obs(random_sprite_scenes(batch, obs_size, seed=123))
+    times = []
+    for step in range(steps + 1):
+        t0 = time.perf_counter()
+        tr.update(obs, IO.make_noise(cfg, batch, step))
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline (iodine) step {step}: {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(batch / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle update() IODINE {obs_size}x{obs_size}/{num_slots} slots/5 iters, batch {batch}, 1 warm-up + {steps} timed steps, "
+                      f"median {t:.2f} s/step"}
+
+
+def committed_traffic(kernel_substr, B, S):
+    """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None.
+    Only used when the file says it was measured at this batch / image size; it is a profile of the same build, not a live counter."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_step_traffic.json")))
+        if tj.get("batch") != B or tj.get("obs_size") != S:
+            return None
+        for k, v in tj["kernels"].items():
+            if kernel_substr in k:
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def timed_region(args, dev, dist, step_fn, prof_mask):
+    """W untimed steps, then exactly K timed steps bracketed by barrier + synchronize; returns (max-over-ranks seconds, prof ms, prof counts)"""
+    from ocrl_amd import _lib
+    L = _lib.lib()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+
+    n = 0
+    last = None
+    for _ in range(args.warmup):
+        last = step_fn(n); n += 1
+    sync()
+    L.ocrl_prof_enable(prof_mask)              # HIP events on the launch stream around the selected kernel families
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step_fn(n); n += 1
+    sync()
+    dt = time.perf_counter() - t0
+    ms = (ctypes.c_double * 8)()
+    cnt = (ctypes.c_longlong * 8)()
+    _lib.check(L.ocrl_prof_collect(ctypes.byref(ms), ctypes.byref(cnt), 8))
+    L.ocrl_prof_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, list(ms), list(cnt), last
+
+
+def mfma_roofline(kernel, flops_per_step, ms, cnt, steps, traffic):
+    """achieved = algorithmic FLOPs of the family's launches in one step / their measured time in one step"""
+    step_ms = ms / max(steps, 1)
+    tf = flops_per_step / (step_ms * 1e-3) / 1e12 if cnt else 0.0
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic, "launches": int(cnt), "avg_ms": round(ms / max(cnt, 1), 4)}
 
 
 def bench_iodine(args, dev, dist, rank, world):
@@ -91,39 +175,49 @@ def bench_iodine(args, dev, dist, rank, world):
         model._opt.step(lr.clip, scale)
         return out[4]
 
-    def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-
-    n = 0
-    for _ in range(args.warmup):
-        step_fn(n); n += 1
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step_fn(n); n += 1
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, ms, cnt, loss = timed_region(args, dev, dist, step_fn, 1 << 1)       # PROF_CONV_OTHER: every conv launch of IODINE is the 3x3 / 64-channel kernel
     if rank == 0:
         ips = B * world * args.steps / dt
         # decoder 1.236 GF per (image, slot, iteration) forward at 64x64: fwd I, in-forward bwd-data I-1, bwd 2I
         dec = 2.0 * 9 * (66 * 64 + 3 * 64 * 64 + 64 * 4) * S * S
         flop_img = dec * K * (5 + 4 + 2 * 5)
-        print(json.dumps({
+        conv_flops_step = 2.0 * 9 * 64 * 64 * B * K * S * S * (cnt[1] / max(args.steps, 1))     # every launch runs on all B*K slot images
+        out = {
             "metric": f"images/sec (node) IODINE pretrain {S}x{S}, {K} slots, 5 iters", "value": round(ips, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"IODINE {S}x{S}, {K} slots, 5 refinement iterations; _forward + backward + all-reduce + L2 clip + Adam "
                                    f"(CPU ARI metric excluded), device RNG; random-N5C4S4S2-style scenes",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
-            "decoder_mfma_frac": round(ips / world * flop_img / (PEAK_MFMA_F32_TFLOPS * 1e12), 4), "final_loss": round(float(loss.item()), 4)}))
+            "roofline": mfma_roofline("conv_fwd_kernel<3,64,64> (IODINE decoder 3x3 convs on B*K slot images: forward, in-forward and backward data gradients)",
+                                      conv_flops_step, ms[1], cnt[1], args.steps, None),
+            "decoder_mfma_frac": round(ips / world * flop_img / (PEAK_MFMA_F32_TFLOPS * 1e12), 4), "final_loss": round(float(loss.item()), 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_iodine(S, K, 8, 3)
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one fresh child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in its environment, the same contract torch.distributed.run provides) BEFORE anything in this process touches the
+    GPU, relay their output, and exit with the worst return code.  The parent never initialises HIP and never re-execs."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    if rc:
+        raise SystemExit(rc)
 
 
 def main():
@@ -140,10 +234,13 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="diagnostic only: the headline number uses the reference default 0.1")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)      # plain `python bench.py --gpus N`: this process only spawns the ranks, it never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -152,7 +249,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ocrl_amd import _lib, ocrs
+    from ocrl_amd import ocrs
     from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
     S, B = args.obs_size, args.batch
     if args.workload == "iodine":
@@ -168,70 +265,55 @@ def main():
     model._module.set_seed(1 + rank)           # per-rank noise / dropout streams
     pool = [scenes_to_obs(random_sprite_scenes(B, S, seed=1000 * rank + i)).to(dev) for i in range(4)]
 
-    def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+    def step_fn(i):
+        return model.update(pool[i % len(pool)], None, i)
 
-    step = 0
-    for _ in range(args.warmup):
-        model.update(pool[step % len(pool)], None, step)
-        step += 1
-    L = _lib.lib()
-    sync()
-    L.ocrl_prof_enable(1 << 0)                 # time the conv5x5/64ch family on the launch stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        metrics = model.update(pool[step % len(pool)], None, step)
-        step += 1
-    sync()
-    dt = time.perf_counter() - t0
-    ms = (ctypes.c_double * 8)()
-    cnt = (ctypes.c_longlong * 8)()
-    _lib.check(L.ocrl_prof_collect(ctypes.byref(ms), ctypes.byref(cnt), 8))
-    L.ocrl_prof_enable(0)
+    # families timed live with HIP events: the 5x5 / 64-channel conv (roofline kernel) and the slot-attention loop (north-star kernel)
+    dt, ms, cnt, metrics = timed_region(args, dev, dist, step_fn, (1 << 0) | (1 << 4) | (1 << 5))
     loss = float(metrics["loss"].item())
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     ips = B * world * args.steps / dt
-    # dominant kernel: conv_fwd_kernel<5,64,64>; algorithmic FLOPs per launch = 2 * (25*64) * 64 * B*S*S
-    conv_flops = 2.0 * 25 * 64 * 64 * B * S * S
-    conv_ms = ms[0] / max(cnt[0], 1)
-    conv_tf = conv_flops / (conv_ms * 1e-3) / 1e12 if cnt[0] else 0.0
-    traffic = None       # HBM bytes per launch from committed rocprofv3 PMC passes (same kernel, same shape), if present
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")))
-        if B == 128 and S == 128:
-            traffic = tj["kernels"]["void conv_fwd_kernel<5, 64, 64>(ConvArgs)"]["hbm_bytes_per_launch"]
-    except Exception:
-        pass
+    K, N = args.num_slots, S * S
+    # dominant kernel conv_fwd_kernel<5,64,64>: 2*25*64*64 FLOP per output pixel.  Launches per step: CNN encoder layers 1-3 forward +
+    # their 3 backward-data passes on B images; with use_bcdec also broadcast-decoder layers 2-3 forward + 2 backward-data on B*K images
+    px = 6 * B * N + (4 * B * K * N if ocr.use_bcdec else 0)
+    conv_flops_step = 2.0 * 25 * 64 * 64 * px
+    name = "SLATE" if args.workload == "slate" else "Slot-Attention (use_bcdec)"
     out = {
-        "metric": f"images/sec (node) SLATE pretrain {S}x{S}, {args.num_slots} slots, 3 iters" if args.workload == "slate" else
-                  f"images/sec (node) Slot-Attention (use_bcdec) pretrain {S}x{S}, {args.num_slots} slots, 3 iters",
+        "metric": f"images/sec (node) {name} pretrain {S}x{S}, {K} slots, 3 iters",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"SLATE {S}x{S}, {args.num_slots} slots, 3 iters, vocab 4096, d_model 192, 4 decoder blocks; full update() step "
-                               f"(fwd+bwd+all-reduce+inf-norm clip+Adam), train mode dropout 0.1, device RNG; random-N5C4S4S2-style scenes",
+        "config": {"workload": f"{name} {S}x{S}, {K} slots, 3 iters" + (", vocab 4096, d_model 192, 4 decoder blocks" if args.workload == "slate" else
+                               ", CNN encoder + slot attention + spatial-broadcast decoder") +
+                               "; full update() step (fwd+bwd+all-reduce+inf-norm clip+Adam), train mode dropout 0.1, device RNG; "
+                               "random-N5C4S4S2-style scenes",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "conv_fwd_kernel<5,64,64> (CNN encoder 5x5 conv, fwd + bwd-data launches)",
-                     "achieved": round(conv_tf, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(conv_tf / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
-                     "launches": int(cnt[0]), "avg_ms": round(conv_ms, 4)},
-        "step_mfma_frac": round(ips / world * 3 * FWD_FLOP_PER_IMAGE.get((S, args.num_slots), 0) / (PEAK_MFMA_F32_TFLOPS * 1e12), 4),
+        "roofline": mfma_roofline("conv_fwd_kernel<5,64,64> (5x5 conv 64->64, forward + backward-data launches" +
+                                  (" of the CNN encoder on B images and of the broadcast decoder on B*K images)" if ocr.use_bcdec else " of the CNN encoder)"),
+                                  conv_flops_step, ms[0], cnt[0], args.steps,
+                                  committed_traffic("conv_fwd_kernel<5, 64, 64>", B, S) if args.workload == "slate" else None),
         "final_loss": round(loss, 4),
     }
-    if args.workload != "slate":
-        out["config"]["workload"] = out["config"]["workload"].replace("SLATE", "Slot-Attention (use_bcdec) SLATE-encoder")
-        out.pop("step_mfma_frac", None)
-    if world == 1 and not args.no_cpu_baseline and args.workload == "slate":
-        out["cpu_baseline"] = cpu_baseline(S, 4, 2)
+    if args.workload == "slate":
+        out["step_mfma_frac"] = round(ips / world * 3 * FWD_FLOP_PER_IMAGE.get((S, K), 0) / (PEAK_MFMA_F32_TFLOPS * 1e12), 4)
+    # north-star kernel (HBM-bound).  Algorithmic bytes of the folded-projection form: the forward reads
+    # x [N,C] once per iteration; the backward reads x once per iteration, writes the running d x once per iteration and re-reads it twice
+    I, C = 3, 64
+    fwd_bytes = B * I * N * C * 4.0
+    bwd_bytes = B * N * C * 4.0 * 8.0                 # x read 3x, d x written 3x and re-read 2x
+    if cnt[4] and cnt[5]:
+        f_ms, b_ms = ms[4] / cnt[4], ms[5] / cnt[5]
+        out["slot_attention"] = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "fwd": {"avg_ms": round(f_ms, 4), "achieved": round(fwd_bytes / f_ms / 1e6, 1), "frac": round(fwd_bytes / f_ms / 1e6 / PEAK_HBM_GBS, 4)},
+                                 "bwd": {"avg_ms": round(b_ms, 4), "achieved": round(bwd_bytes / b_ms / 1e6, 1), "frac": round(bwd_bytes / b_ms / 1e6 / PEAK_HBM_GBS, 4)},
+                                 "note": "algorithmic bytes of the folded-projection form (12.6 MB/img forward at N=16384; the reference's materialised k|v "
+                                         "form would move 75.5 MB/img); MFMA-busy / HBM PMC counters for these kernels: profiles/r02_pmc_*"}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec))
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

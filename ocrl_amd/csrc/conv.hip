@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, (ConvCfg<KS, CIN>::WGS)) void conv_fwd_kernel(
             const int prow = (wave + (more ? ky : 0)) * HW_ + li + (more ? kx : 0);
             const float* arow = smem + prow * LDH + (SWZ ? 0 : 4 * lh);
             const int sv = (4 * lh) ^ ((prow & 15) * 4);
-            const float* wn = wl + ((p.diag || !more) ? 0 : (size_t)tn * NCH * COUT * 8);
+            const float* wn = wl + (!more ? 0 : (size_t)tn * NCH * COUT * 8);
 #pragma unroll
             for (int cc = 0; cc < NCH; ++cc) {
                 const float4 a = ra[cc], b0 = rb0[cc], b1 = rb1[cc];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, (ConvCfg<KS, CIN>::WGS)) void conv_fwd_kernel(
                 const int it = tap * NCH + cc;
                 const float4 b0 = nb0, b1 = nb1;
                 if (it + 1 < NIT) {
-                    const size_t wo = p.diag ? 0 : (size_t)(it + 1) * COUT * 8;
+                    const size_t wo = (size_t)(it + 1) * COUT * 8;
                     nb0 = *reinterpret_cast<const float4*>(wl + wo);
                     nb1 = *reinterpret_cast<const float4*>(wl + wo + 32 * 8);
                 }
@@ -365,7 +365,6 @@ static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
 
 int conv_fwd_launch(const ConvArgs& a_in, int KS, int CIN, int COUT, hipStream_t st) {
     ConvArgs a = a_in;
-    { static int dg = -1; if (dg < 0) { const char* e = getenv("OCRL_CONV_DIAG"); dg = e ? atoi(e) : 0; } a.diag = dg; }
     OCRL_REQUIRE(COUT == 64, "conv: COUT must be 64 (got %d)", COUT);
     OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "conv: empty input");
     OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.Wp & 15) == 0, "conv: X/Wp must be 16-byte aligned");

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
             store_tile<BM, AKC>(As0, ra);
             store_tile<BN, BKC>(Bs0, rb);
             __syncthreads();
-            if (kt + 1 < kt1 && p.diag != 2) {                     // OCRL_GEMM_DIAG=2: only the first k-tile is fetched
+            if (kt + 1 < kt1) {
                 const int k0 = (kt + 1) * BK;
                 load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
                 load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
     // Fast path: every 32x32 accumulator tile goes through a wave-private LDS patch and leaves as float4 rows — 4x fewer store
     // (and mask / residual load) instructions, full 128-byte lines, and one dropout draw per 4 outputs instead of one per output.
     const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!R || ((p.ldr & 3) == 0 && (((uintptr_t)R) & 15) == 0)) &&
-                     (!Mk || ((p.ldmask & 3) == 0 && (((uintptr_t)Mk) & 15) == 0)) && (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && p.diag != 1;
+                     (!Mk || ((p.ldmask & 3) == 0 && (((uintptr_t)Mk) & 15) == 0)) && (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
     if (vec) {
         __syncthreads();                                   // the operand tiles are dead: their LDS becomes four staging patches
         float* patch = smem + wave * (32 * 36);
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                     }
                     if (R) v += R[(size_t)row * p.ldr + col];
                 }
-                if (p.diag == 1 && v != 12345.678f) continue;      // OCRL_GEMM_DIAG=1: timing without the output stores
                 C[(size_t)row * p.ldc + col] = v;
             }
         }
@@ -457,15 +456,8 @@ static int launch_tr(const GemmArgs& a, hipStream_t st) {
     return launch_cfg<64, 64, AKC, BKC>(a, st);
 }
 
-static int gemm_diag() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OCRL_GEMM_DIAG"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 int gemm_launch(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
-    a.diag = gemm_diag();
     OCRL_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d %d %d", a.M, a.N, a.K);
     OCRL_REQUIRE(a.batch >= 1 && a.splitk >= 1, "gemm: bad batch/splitk");
     if (a.akc) OCRL_REQUIRE(a.K % 4 == 0 && a.lda % 4 == 0, "gemm: A k-contiguous needs K,lda %% 4 == 0 (K=%d lda=%d)", a.K, a.lda);

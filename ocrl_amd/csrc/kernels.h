@@ -37,7 +37,6 @@ struct GemmArgs {
     float adrop_p = 0.f; unsigned adrop_site = 0; int adrop_ld = 0;
     // fused bias gradient for the dW form (akc == 0): bias_out[m] = sum_k A(m,k)  (partials per split at stride sBias)
     float* bias_out = nullptr; long long sBias = 0;
-    int diag = 0;                         // development diagnostic (OCRL_GEMM_DIAG): wrong results, timing only
 };
 int gemm_launch(const GemmArgs& a, hipStream_t st);
 int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
@@ -60,7 +59,6 @@ struct ConvArgs {
     const float* posmap = nullptr;  // [H,W,COUT] added after bias/relu
     const float* mask = nullptr;    // [B,H,W,COUT]: output zeroed where mask <= 0 (ReLU backward)
     int mask_elu = 0;               // mask holds ELU outputs: v *= (m > 0 ? 1 : m + 1)
-    int diag = 0;                   // development diagnostic (OCRL_CONV_DIAG): wrong results, timing only
 };
 struct WgradArgs {
     const float* X = nullptr;       // [B,H,W,CIN]

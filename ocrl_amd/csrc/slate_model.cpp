@@ -141,7 +141,7 @@ void SlateModel::layout_workspace(bool commit) {
     scratch_ = carve(nullptr, scratch_floats_);
     scratch2_ = cfg.use_bcdec ? scratch_ : carve(nullptr, scratch_floats_);
     obs8_ = carve("obs8", BN * 8);
-    e1_ = carve(nullptr, BN * 64); e2_ = carve(nullptr, BN * 64); e3_ = carve(nullptr, BN * 64); e4_ = carve("feats", BN * 64);
+    e1_ = carve("enc1", BN * 64); e2_ = carve("enc2", BN * 64); e3_ = carve("enc3", BN * 64); e4_ = carve("feats", BN * 64);
     posmap_ = carve(nullptr, (size_t)N * C); gridT_ = carve(nullptr, (size_t)N * 4);
     ln0_ = carve(nullptr, BN * 64); ln0_mean_ = carve(nullptr, BN); ln0_rstd_ = carve(nullptr, BN);
     h1_ = carve(nullptr, BN * 64); x_ = carve("sa_inputs", BN * 64);

@@ -127,6 +127,9 @@ class Iodine_Module(nn.Module):
             named[p.name].grad = eng.view(eng.flat_g, p) if p.name != "slot_init" else None     # never receives a gradient (iodine_module.py:76-78)
         self.engine = eng
         self._max_batch = batch
+        pending, self._pending_opt = getattr(self, "_pending_opt", None), None
+        if pending is not None:       # optimiser state loaded before .to(device)
+            pending[0].load_state_dict(pending[1])
         torch.cuda.synchronize(eng.device)
 
     def _need(self, obs):
@@ -155,7 +158,7 @@ class Iodine_Module(nn.Module):
         image = self._need(image)
         B, K, S, L = image.shape[0], self.num_slots, self.img_size, self.slot_size
         noise, self._injected_noise = self._injected_noise, None
-        m = self.engine.forward(image, self._next_seed(), noise)
+        m = self.engine.forward(image, self._next_seed(), noise).clone()     # fresh metric tensors (the buffer is reused by the next forward)
         eng = self.engine
         slots = eng.tensor("slots", (B, K, L))
         masks = eng.tensor("masks", (B, K, 1, S, S))
@@ -211,8 +214,10 @@ class Iodine(Base):
         if not hasattr(self, "_opt"):
             return {}
         lr = self._config.learning
-        if hasattr(lr, "clip") and float(getattr(lr, "clip_norm_type", 2.0)) != 2.0:
-            raise NotImplementedError("IODINE HIP backend: clip_norm_type must be 2.0 (the reference configuration)")
+        # ocrs/base.py:66: a missing clip_norm_type means 'inf' in the reference; this backend implements the L2 clip of configs/ocr/iodine*.yaml only
+        if hasattr(lr, "clip") and str(getattr(lr, "clip_norm_type", "inf")) not in ("2", "2.0"):
+            raise NotImplementedError("IODINE HIP backend: learning.clip_norm_type must be 2.0 (the reference configuration; absent = 'inf' in ocrs/base.py:66)")
+        self._module._step_seed = int(step) * 16      # RNG streams follow the global step, so resume does not replay them
         metrics = self.get_loss(obs, masks)
         self._module.backward()
         scale = allreduce_grads_(self._module.engine.flat_g)

@@ -226,6 +226,9 @@ class SLATE_Module(nn.Module):
             b.data = b.data.to(eng.device)
         self.engine = eng
         self._max_batch = batch
+        pending, self._pending_opt = getattr(self, "_pending_opt", None), None
+        if pending is not None:       # optimiser state loaded before .to(device), as the reference's callers do (sb3s/ocr_extractor.py:33-36)
+            pending[0].load_state_dict(pending[1])
         torch.cuda.synchronize(eng.device)
 
     def _need(self, obs):
@@ -280,7 +283,8 @@ class SLATE_Module(nn.Module):
         obs = self._need(obs)
         B = obs.shape[0]
         noise, self._injected_noise = self._injected_noise, None
-        m = self.engine.forward(obs, self._tau, self.training, self._next_seed(), noise)
+        # fresh tensors, as the reference returns: the engine's metrics buffer is overwritten by the next forward
+        m = self.engine.forward(obs, self._tau, self.training, self._next_seed(), noise).clone()
         if self._use_bcdec:        # slate_module.py:218-225
             metrics = {"loss": m[2], "mse": m[0].detach(), "ari": 0}
         else:
@@ -386,8 +390,11 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         eng = self._module.engine
-        if eng is None:
-            raise RuntimeError("move the model to the GPU (.to(device)) before loading optimiser state")
+        if eng is None:         # Base.load() before .to(device) (ocrs/base.py:83-88 callers): applied when the flat buffers exist
+            self._module._pending_opt = (self, sd)
+            for g, sg in zip(self.param_groups, sd["param_groups"]):
+                g["lr"] = sg["lr"]
+            return
         named = {id(p): n for n, p in self._module.named_parameters()}
         spec = {p.name: p for p in eng.params}
         for g, sg, ids in zip(self.param_groups, sd["param_groups"], self._indexed()):
@@ -432,6 +439,7 @@ class SLATE(Base):
         """ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74: schedules -> loss -> backward ->
         [gradient all-reduce over RCCL when torch.distributed is initialised] -> inf-norm clip -> Adam."""
         self._module.update_tau(step)
+        self._module._step_seed = int(step) * 16      # noise / dropout streams are a function of (seed, rank, global step): a resumed run replays nothing
         lr = self._config.learning
         warm = linear_warmup(step, 0, 1, 0, lr.lr_warmup_steps)
         decay = math.exp(step / lr.lr_half_life * math.log(0.5))

@@ -56,7 +56,7 @@ class _PoolFn(torch.autograd.Function):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(L.ocrl_pool_transformer_fwd(_lib.ptr(slots), arr, _lib.ptr(pos), _lib.ptr(out), B, K, Din, d, nhead, ff, nl, drop_p, seed, _lib.ptr(ws), n, st))
         ctx.geom, ctx.drop_p, ctx.seed, ctx.ws, ctx.ps, ctx.slots = geom, drop_p, seed, ws, ps, slots
-        ctx.need_dslots = slots.requires_grad
+        ctx.need_dslots = ctx.needs_input_grad[0]      # read from the autograd node: the converted copy above carries no requires_grad
         return out
 
     @staticmethod

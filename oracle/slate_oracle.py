@@ -287,6 +287,7 @@ def cnn_encode(P, obs, grid=None):
     x = F.conv2d(x, P["_enc._encoder.3.weight"], P["_enc._encoder.3.bias"], padding=2)
     if grid is None:
         grid = position_grid(obs.shape[-1])
+    grid = grid.to(x.dtype)             # fp64 runs of the restatement (conditioning studies) keep every operand in one dtype
     x = x + F.conv2d(grid, P["_enc_pos.channels_map.weight"], P["_enc_pos.channels_map.bias"])
     return x.permute(0, 2, 3, 1).flatten(1, 2)
 
@@ -389,6 +390,7 @@ def broadcast_decoder(P, slots, cfg, grid=None):
     S = cfg.obs_size
     if grid is None:
         grid = position_grid(S)
+    grid = grid.to(slots.dtype)
     x = slots.reshape(B * K, D, 1, 1).expand(B * K, D, S, S)
     x = x + F.conv2d(grid, P["_dec._pos_emb.channels_map.weight"], P["_dec._pos_emb.channels_map.bias"])
     for i in range(3):

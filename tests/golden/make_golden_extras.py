@@ -1,0 +1,177 @@
+"""Golden vectors for the rows of SURVEY.md §8 that make_golden.py does not cover.  Runs ONLY in the build container (imports the
+reference modules from /root/reference exactly as make_golden.py does); writes data-only fixtures:
+
+  slate_a128_eval.npz    config A (128x128, 6 slots, 3 iterations, vocab 4096, 4 blocks), B=1: one reference update() (loss terms, norm,
+                         per-parameter checksums) + forward intermediates and gradient checksums at the next step
+  slate_surface.npz      real widths at 16x16: SLATE_Module.forward plain / with_masks / with_attns / use_cnn_feat (slate_module.py:181-196),
+                         _gen_imgs tokens + image + get_loss(with_mse=True)['mse'] (slate_module.py:163-179,234-237)
+  slate_masks_bcdec.npz  use_bcdec get_loss(obs, masks): mse and the reported ARI (slate_module.py:207-225, utils/tools.py:309-320), plus the
+                         label maps the ARI was computed from
+  slate_init_stats.npz   per-tensor statistics of the reference constructors' initialisation (ocrs/common/networks.py:6-74,
+                         slot_attn.py:133-136, transformer.py:53-58,193-198) at the 64x64 configuration
+
+    python tests/golden/make_golden_extras.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_golden as MG  # noqa: E402
+
+SURF = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2)
+BCM = dict(obs_size=16, vocab_size=256, num_slots=5, num_iterations=3, num_dec_blocks=1, use_bcdec=True)
+
+
+def build(SLATE, cfg, use_cnn_feat=False):
+    from oracle import slate_oracle as O
+    torch.manual_seed(0)
+    ocr, env = MG.ref_config(cfg)
+    ocr.use_cnn_feat = use_cnn_feat
+    model = SLATE(ocr, env)
+    P = O.formula_params(cfg)
+    sd = model._module.state_dict()
+    model._module.load_state_dict({k: (P[k] if k in P else sd[k]) for k in sd})
+    model.eval()
+    return model, P
+
+
+def seeded_masks(B, K1, S, seed):
+    """ground-truth masks [B,K+1,1,S,S] one-hot over K+1 (last = background), blocky regions from a seeded label map"""
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, K1, (B, S // 4, S // 4), generator=g)
+    lab = lab.repeat_interleave(4, 1).repeat_interleave(4, 2)
+    return torch.nn.functional.one_hot(lab, K1).permute(0, 3, 1, 2).unsqueeze(2).float()
+
+
+def run_surface(SLATE):
+    from oracle import slate_oracle as O
+    cfg = O.default_cfg(**SURF)
+    B, seed = 2, 13
+    model, P = build(SLATE, cfg)
+    mod = model._module
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(seed + 1000))
+    noise = O.make_noise(cfg, B, seed)
+    out = {"B": B, "seed": seed}
+    with torch.no_grad():
+        # the only draw of forward() is the slot-initialisation normal: replay make_noise's third draw
+        def reseed():
+            torch.manual_seed(seed)
+            torch.empty_like(noise["z"]).exponential_()
+            torch.empty_like(noise["z"]).exponential_()
+        reseed(); slots = model(obs)
+        reseed(); s_m, masks = model(obs, with_masks=True)
+        reseed(); s_a, attns = model(obs, with_attns=True)
+        assert torch.equal(slots, s_m) and torch.equal(slots, s_a)
+        out["slots"] = slots.numpy().copy()
+        out["with_masks"] = masks.numpy().copy()
+        out["with_attns"] = attns.numpy().copy()
+        # autoregressive generation from those slots
+        img = mod._gen_imgs(slots)
+        proj = mod._slotproj(slots)
+        inp = mod._bos_token().expand(B, 1, -1)
+        toks = []
+        for t in range(mod._enc_size ** 2):     # the same loop, keeping the token ids (the reference only keeps one-hots)
+            nxt = mod._out(mod._tfdec(mod._z_pos(inp), proj))[:, -1:].argmax(-1)
+            toks.append(nxt)
+            inp = torch.cat([inp, mod._dict(torch.nn.functional.one_hot(nxt, cfg.vocab_size))], 1)
+        toks = torch.cat(toks, 1)
+        zg = torch.nn.functional.one_hot(toks, cfg.vocab_size).transpose(1, 2).float().reshape(B, -1, mod._enc_size, mod._enc_size)
+        assert torch.equal(mod._dvae.decode(zg), img), "token replay differs from _gen_imgs"
+        out["gen_tokens"] = toks.numpy().astype(np.int32)
+        out["gen_image"] = img.numpy().copy()
+        torch.manual_seed(seed)
+        model._module.update_tau(0)
+        m = mod.get_loss(obs, None, with_mse=True)
+        out["with_mse.mse"] = np.float64(m["mse"].item())
+        out["with_mse.loss"] = np.float64(m["loss"].item())
+        # oracle agreement (pins the restatement's pieces used by the GPU test)
+        feats = O.cnn_encode(P, obs)
+        so, ao = O.slot_encoder(P, feats, noise["slots"], cfg)
+        rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+        assert rel(so, slots) < 2e-5 and rel(ao.transpose(-1, -2).reshape(masks.shape), masks) < 2e-5
+    # use_cnn_feat
+    model_f, _ = build(SLATE, cfg, use_cnn_feat=True)
+    with torch.no_grad():
+        f = model_f(obs)
+    assert f.shape == (B, cfg.obs_size ** 2, 64 + 3) and model_f.rep_dim == 67 and model_f.num_slots == cfg.obs_size ** 2
+    out["cnn_feat"] = f.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "slate_surface.npz"), **out)
+    print("[surface] wrote slate_surface.npz; gen mse", out["with_mse.mse"])
+
+
+def run_masks_bcdec(SLATE):
+    from oracle import slate_oracle as O
+    cfg = O.default_cfg(**BCM)
+    B, seed = 3, 17
+    model, P = build(SLATE, cfg)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(seed + 1000))
+    masks = seeded_masks(B, cfg.num_slots + 1, cfg.obs_size, seed)
+    with torch.no_grad():
+        torch.manual_seed(seed)
+        m = model._module.get_loss(obs, masks)
+        torch.manual_seed(seed)
+        m_sl = None
+    out = {"B": B, "seed": seed, "mse": np.float64(m["mse"].item()), "loss": np.float64(m["loss"].item()), "ari": np.float64(m["ari"])}
+    # the SLATE branch executes the same mask code but does not report ari (slate_module.py:231): pin its loss with masks given
+    cfg2 = O.default_cfg(**dict(BCM, use_bcdec=False))
+    model2, _ = build(SLATE, cfg2)
+    with torch.no_grad():
+        torch.manual_seed(seed)
+        m2 = model2._module.get_loss(obs, masks)
+    assert "ari" not in m2
+    out["slate.loss"] = np.float64(m2["loss"].item())
+    out["slate.keys"] = np.array(sorted(m2.keys()))
+    np.savez_compressed(os.path.join(HERE, "slate_masks_bcdec.npz"), **out)
+    print("[masks] wrote slate_masks_bcdec.npz; ari", out["ari"], "mse", out["mse"])
+
+
+def run_init_stats(SLATE):
+    from oracle import slate_oracle as O
+    cfg = O.default_cfg(obs_size=64, num_slots=6, use_bcdec=False)
+    names, rows = None, []
+    for s in range(4):          # four independent constructions: mean statistics, so the check is not a single draw
+        torch.manual_seed(100 + s)
+        ocr, env = MG.ref_config(cfg)
+        model = SLATE(ocr, env)
+        cur, r = [], []
+        for n, p in model._module.named_parameters():
+            if not p.requires_grad:
+                continue
+            t = p.detach().double()
+            orth = -1.0
+            if n.endswith("gru.weight_hh"):
+                orth = (t.T @ t - torch.eye(t.shape[1], dtype=torch.float64)).abs().max().item()
+            cur.append(n)
+            r.append([t.mean().item(), t.std(unbiased=False).item(), t.abs().max().item(), orth])
+        names = cur
+        rows.append(r)
+    rows = np.array(rows)           # [4, P, 4]
+    np.savez_compressed(os.path.join(HERE, "slate_init_stats.npz"), names=np.array(names), stats=rows.mean(0), stats_sd=rows.std(0))
+    print("[init] wrote slate_init_stats.npz for", len(names), "tensors")
+
+
+def main():
+    from oracle import slate_oracle as O
+    SLATE = MG.import_reference()
+    torch.set_num_threads(8)
+    if "--only-a128" not in sys.argv:
+        run_surface(SLATE)
+        run_masks_bcdec(SLATE)
+        run_init_stats(SLATE)
+    a128 = O.default_cfg(obs_size=128, num_slots=6)
+    # At this size the closed-form weights make a few gradient tensors ill-conditioned in fp32: two fp32 CPU evaluations (the reference
+    # modules and the oracle) differ by ~1e-2 of such a tensor's max, and the fp32 oracle is as far from its own fp64 run (measured:
+    # _dvae._decoder.0.m.weight 1.1e-2, _tfdec.blocks.3.ffn.0.weight 7e-3).  Loss terms, norm and the parameters after update() agree to
+    # 1e-7; the GPU test therefore pins those tightly and grades gradients against an fp64 run of the oracle instead.
+    MG.run_case("a128_eval", a128, B=1, seed=9, train_dropout=False, n_steps=1, SLATE=SLATE, full=False, grad_tol=5e-2)
+
+
+if __name__ == "__main__":
+    main()

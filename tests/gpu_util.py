@@ -37,3 +37,28 @@ def load_params(engine, P):
     for p in engine.params:
         engine.view(engine.flat_p, p).copy_(P[p.name].to(engine.device).reshape(p.shape))
     torch.cuda.synchronize()
+
+
+def reference_style_config(cfg, use_cnn_feat=False):
+    """(ocr_config, env_config) namespaces in the reference's layout (configs/ocr/slate.yaml) for an oracle cfg"""
+    from types import SimpleNamespace as NS
+    ocr = NS(name="SLATE", tau_start=cfg.tau_start, tau_final=cfg.tau_final, tau_steps=cfg.tau_steps, hard=cfg.hard, use_cnn_feat=use_cnn_feat,
+             use_bcdec=cfg.use_bcdec, dvae=NS(vocab_size=cfg.vocab_size, d_model=cfg.d_model), cnn=NS(hidden_size=cfg.cnn_hidden),
+             slotattr=NS(num_iterations=cfg.num_iterations, num_slots=cfg.num_slots, num_slot_heads=cfg.num_slot_heads, slot_size=cfg.slot_size,
+                         mlp_hidden_size=cfg.mlp_hidden, pos_channels=4),
+             tfdec=NS(num_dec_blocks=cfg.num_dec_blocks, num_dec_heads=cfg.num_dec_heads),
+             learning=NS(lr_half_life=cfg.lr_half_life, lr_dvae=cfg.lr_dvae, lr_enc=cfg.lr_enc, lr_dec=cfg.lr_dec, lr_warmup_steps=cfg.lr_warmup_steps,
+                         dropout=cfg.dropout, clip=cfg.clip))
+    return ocr, NS(obs_size=cfg.obs_size, obs_channels=cfg.obs_channels)
+
+
+def build_wrapper(cfg, P, use_cnn_feat=False, device="cuda:0"):
+    """ocrs.SLATE (the drop-in wrapper) holding the oracle's closed-form weights, on the GPU, eval mode"""
+    from ocrl_amd import ocrs
+    ocr, env = reference_style_config(cfg, use_cnn_feat)
+    model = ocrs.SLATE(ocr, env)
+    sd = model._module.state_dict()
+    model._module.load_state_dict({k: (P[k] if k in P else sd[k]) for k in sd})
+    model.to(device)
+    model.eval()
+    return model

@@ -21,7 +21,7 @@ def t(f, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 ms = t(lambda: _lib.check(L.ocrl_conv2d_fwd(P(x), P(w), P(b), P(y), B, S, S, 64, 64, 5, 1, P(ws), None)))
-print(f"conv fwd 5x5 64->64 B{B} S{S}: {ms:.3f} ms {fl/ms/1e9:.1f} TFLOP/s diag={os.environ.get('OCRL_CONV_DIAG','0')}")
+print(f"conv fwd 5x5 64->64 B{B} S{S}: {ms:.3f} ms {fl/ms/1e9:.1f} TFLOP/s")
 n = L.ocrl_conv2d_wgrad_ws_floats(B, S, S, 5, 64)
 ws2 = torch.empty(n, device="cuda"); dw = torch.empty(64, 64, 5, 5, device="cuda")
 ms = t(lambda: _lib.check(L.ocrl_conv2d_bwd_weight(P(x), P(y), P(dw), None, B, S, S, 64, 64, 5, P(ws2), n, None)))

@@ -4,13 +4,13 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ocrl_amd import _lib
-from oracle import pooling_oracle as PO            # parameter inventory / closed-form weights only (bench tooling, not the product path)
+from types import SimpleNamespace
+from ocrl_amd.poolings.transformer import Transformer_Module
 L = _lib.lib()
 p = _lib.ptr
-cfg = PO.default_cfg()
-P = PO.formula_params(cfg)
-names = [n for n, _ in PO.param_shapes(cfg)]
-w = [P[n].cuda() for n in names]; g = [torch.empty_like(t) for t in w]
+cfg = SimpleNamespace(rep_dim=192, num_slots=6, d_model=128, nhead=8, num_layers=1, dim_feedforward=2048, dropout=0.1, pos_emb="None")
+torch.manual_seed(0)
+w = [t.detach().cuda().contiguous() for t in Transformer_Module(cfg.rep_dim, cfg.num_slots, cfg)._param_list()]; g = [torch.empty_like(t) for t in w]
 arr = (ctypes.c_void_p * len(w))(*[t.data_ptr() for t in w]); garr = (ctypes.c_void_p * len(g))(*[t.data_ptr() for t in g])
 K, Din, d, h, ff, nl = cfg.num_slots, cfg.rep_dim, cfg.d_model, cfg.nhead, cfg.dim_feedforward, cfg.num_layers
 def t(f, n=50):
