@@ -144,13 +144,13 @@ void SlateModel::layout_workspace(bool commit) {
     e1_ = carve("enc1", BN * 64); e2_ = carve("enc2", BN * 64); e3_ = carve("enc3", BN * 64); e4_ = carve("feats", BN * 64);
     posmap_ = carve(nullptr, (size_t)N * C); gridT_ = carve(nullptr, (size_t)N * 4);
     ln0_ = carve(nullptr, BN * 64); ln0_mean_ = carve(nullptr, BN); ln0_rstd_ = carve(nullptr, BN);
-    h1_ = carve(nullptr, BN * 64); x_ = carve("sa_inputs", BN * 64);
+    h1_ = carve("sa_mlp_hidden", BN * 64); x_ = carve("sa_inputs", BN * 64);
     slots0_ = carve("slots0", BK * D); slot_noise_ = carve(nullptr, BK * D); slots_ = carve("slots", BK * D);
     attn_ = carve("attn", BN * K);
     const SaSave so = sa_save_layout(C, D, H);
     const SaGrad go = sa_grad_layout(C, D, H);
     const SaWts wo = sa_wts_layout(C, D, H);
-    sa_save_ = carve(nullptr, BK * I * so.ld);
+    sa_save_ = carve("sa_save", BK * I * so.ld);
     sa_grows_ = carve(nullptr, BK * I * go.ld);
     sa_wts_ = carve(nullptr, wo.total);
     sa_small_ = carve(nullptr, B * (4 * D + 2 * C));
@@ -169,7 +169,7 @@ void SlateModel::layout_workspace(bool commit) {
         const size_t BKN = BK * (size_t)N;
         bc_Wc_ = carve(nullptr, 25 * 64 * 5 + 64); bc_W1r_ = carve(nullptr, (size_t)25 * 64 * D); bc_P1_ = carve(nullptr, (size_t)N * 64);
         bc_M_ = carve(nullptr, BK * 1600); bc_T_ = carve(nullptr, BK * 1600);
-        bc_c1_ = carve(nullptr, BKN * 64); bc_c2_ = carve(nullptr, BKN * 64); bc_c3_ = carve(nullptr, BKN * 64);
+        bc_c1_ = carve("bc_c1", BKN * 64); bc_c2_ = carve("bc_c2", BKN * 64); bc_c3_ = carve("bc_c3", BKN * 64);
         bc_out4_ = carve(nullptr, BKN * 4); bc_dout4_ = carve(nullptr, BKN * 4);
         bc_gA_ = carve(nullptr, BKN * 64); bc_gB_ = carve(nullptr, BKN * 64);
         for (int i = 0; i < 2; ++i) { bc_pk_[i] = carve(nullptr, 25 * 64 * 64); bc_pkb_[i] = carve(nullptr, 25 * 64 * 64); }
@@ -179,15 +179,16 @@ void SlateModel::layout_workspace(bool commit) {
         recon_ = carve("recon", BN * 4);
     } else {
     patches_ = carve("patches", BT * 16 * cfg.obs_channels);
-    for (int i = 0; i < 7; ++i) de_[i] = carve(nullptr, BT * 64);
+    for (int i = 0; i < 7; ++i) de_[i] = carve(fmt("dvae_enc%d", i).c_str(), BT * 64);
     zraw_ = carve("zraw", BT * V);
     z_ = carve("z", BT * V);
     zdec_ = cfg.hard ? carve("z_st", BT * V) : z_;
     tokens_ = reinterpret_cast<int*>(carve("tokens", BT));
-    dd0_ = carve(nullptr, BT * 64); dd1_ = carve(nullptr, BT * 64); dd2_ = carve(nullptr, BT * 64); dd3_ = carve(nullptr, BT * 64);
-    dd4_ = carve(nullptr, BT * 256); ps1_ = carve(nullptr, BT * 256);
-    dd6_ = carve(nullptr, BT * 256); dd7_ = carve(nullptr, BT * 256); dd8_ = carve(nullptr, BT * 256);
-    dd9_ = carve(nullptr, BT * 1024); ps2_ = carve(nullptr, BN * 64);
+    // post-activation outputs of the dVAE decoder blocks (named: the parity tests read their ReLU masks)
+    dd0_ = carve("dvae_dec0", BT * 64); dd1_ = carve("dvae_dec1", BT * 64); dd2_ = carve("dvae_dec2", BT * 64); dd3_ = carve("dvae_dec3", BT * 64);
+    dd4_ = carve("dvae_dec4", BT * 256); ps1_ = carve(nullptr, BT * 256);
+    dd6_ = carve("dvae_dec6", BT * 256); dd7_ = carve("dvae_dec7", BT * 256); dd8_ = carve("dvae_dec8", BT * 256);
+    dd9_ = carve("dvae_dec9", BT * 1024); ps2_ = carve(nullptr, BN * 64);
     recon_ = carve("recon", BN * 4); drecon_ = carve(nullptr, BN * 4);
     for (int i = 0; i < 2; ++i) { dw_fwd_[i] = carve(nullptr, 9 * 64 * 64); dw_bwd_[i] = carve(nullptr, 9 * 64 * 64); }
     w11p_ = carve(nullptr, 4 * 64);
@@ -201,7 +202,7 @@ void SlateModel::layout_workspace(bool commit) {
         k.cq = carve(nullptr, BT * d); k.ck = carve(nullptr, BK * d); k.cv = carve(nullptr, BK * d);
         k.cP = carve(nullptr, B * NH * (size_t)T * K); k.cao = carve(nullptr, BT * d); k.x2 = carve(nullptr, BT * d);
         k.ln3 = carve(nullptr, BT * d); k.ln3_mean = carve(nullptr, BT); k.ln3_rstd = carve(nullptr, BT);
-        k.f1 = carve(nullptr, BT * 4 * d); k.x3 = carve(nullptr, BT * d);
+        k.f1 = carve(fmt("blk%d.ffn_hidden", b).c_str(), BT * 4 * d); k.x3 = carve(nullptr, BT * d);
     }
     attn_delta_ = carve(nullptr, B * NH * (size_t)T);
     lnf_ = carve("dec_out", BT * d); lnf_mean_ = carve(nullptr, BT); lnf_rstd_ = carve(nullptr, BT);

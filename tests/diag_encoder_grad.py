@@ -21,6 +21,7 @@ from ocrl_amd import _lib                                       # noqa: E402
 from ocrl_amd.engine import SlateEngine                         # noqa: E402
 
 PRE = {}
+FORCED_MASKS = None       # per layer [B,64,S,S] bool: use these ReLU masks instead of (pre > 0)
 
 
 def cnn_encode_hooked(P, obs, grid=None):
@@ -29,7 +30,7 @@ def cnn_encode_hooked(P, obs, grid=None):
         pre = F.conv2d(x, P[f"_enc._encoder.{i}.m.weight"], P[f"_enc._encoder.{i}.m.bias"], padding=2)
         pre.retain_grad()
         PRE[i] = (x, pre)
-        x = F.relu(pre)
+        x = F.relu(pre) if FORCED_MASKS is None else pre * FORCED_MASKS[i].to(pre.dtype)
     pre = F.conv2d(x, P["_enc._encoder.3.weight"], P["_enc._encoder.3.bias"], padding=2)
     pre.retain_grad()
     PRE[3] = (x, pre)
@@ -85,6 +86,16 @@ def main():
         flips = ((act > 0) != (pre > 0))
         print(f"  layer {i}: ReLU mask flips HIP vs fp64: {int(flips.sum())} of {flips.numel()}; smallest |pre| {pre.abs().min().item():.2e}; "
               f"|pre| at flips {pre[flips].abs().tolist()[:8]}; activation error {relerr(act, F.relu(pre)):.2e}")
+    # the same fp64 run with the ReLU masks of the HIP forward: if mask flips are the whole story, the error collapses
+    global FORCED_MASKS
+    FORCED_MASKS = [(eng.tensor(name, (B, S, S, 64)).cpu() > 0).permute(0, 3, 1, 2) for name in ("enc1", "enc2", "enc3")]
+    t64m, _ = run_oracle(cfg, P, obs, noise, step, torch.float64)
+    FORCED_MASKS = None
+    print(f"[{tag}] against an fp64 run that uses the HIP forward's ReLU masks in the CNN encoder:")
+    for p in eng.params:
+        if p.name.startswith("_enc."):
+            ref = t64m.P[p.name].grad.reshape(p.shape)
+            print(f"  {p.name:34s} HIP {relerr(eng.view(eng.flat_g, p), ref, floor=1e-5 * gmax):.2e}")
     # unit kernels on the oracle's operands
     L = _lib.lib()
     for i in (1, 2, 3):

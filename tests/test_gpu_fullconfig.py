@@ -5,11 +5,18 @@
     every forward stage and every parameter gradient;
   * the batch-additivity property at 256x256 (B=2 vs its halves).
 
-Gradient tolerance.  With the closed-form test weights a handful of gradient tensors are ill-conditioned in fp32 at these sizes: the
-fp32 oracle itself sits up to 1e-2 of such a tensor's max away from an fp64 run of the same oracle (and from the reference modules, see
-make_golden_extras.py).  A fixed max-norm tolerance is therefore either vacuous or unmeetable; the bar used here is relative to what fp32
-arithmetic achieves on that very tensor:   err_HIP(vs fp64) <= max(GRAD_FACTOR * err_fp32-oracle(vs fp64), GRAD_FLOOR),
-errors in max-norm relative to the tensor's max (floored at 1e-5 x the largest gradient)."""
+Gradient tolerance.  At these sizes a step evaluates 10^7-10^8 ReLU pre-activations, and a few of them lie inside fp32 rounding noise
+of zero; whichever way such a unit's mask falls, one token's / pixel's contribution (~1/T .. 1/N of a weight-gradient row) appears or
+vanishes.  Any two fp32 evaluations therefore differ by up to ~1e-2 of a tensor's max on the tensors upstream of a flip: the fp32 oracle
+against an fp64 run of itself, the oracle against the reference modules (make_golden_extras.py), and this backend against either
+(tests/diag_encoder_grad.py shows the mechanism on the 64x64 case: one flipped mask at |pre-activation| = 4.9e-8 explains all of a
+2.7e-4 error, the weight-gradient kernel itself is at 2.8e-7).  A fixed max-norm tolerance is then either vacuous or unmeetable, so the
+bar is stated relative to what the reference's own fp32 arithmetic achieves on the same input, against the fp64 run:
+    per tensor:  err_HIP <= max(GRAD_FACTOR * err_fp32-oracle on that tensor, GRAD_FLOOR,  worst err_fp32-oracle over all tensors)
+i.e. within 4x of fp32's error on a tensor fp32 handles well, and never further from the exact gradient than the reference arithmetic is
+at its worst on that input; and, with the ReLU decisions of the HIP forward imposed on the fp64 run (tests/gpu_util.py), every tensor within
+GRAD_TOL.  Errors are max-norm, relative to the tensor's max (floored at 1e-5 x the largest gradient).  The ReLU masks
+of both oracle runs are recorded and the flip counts logged next to the errors."""
 import os
 
 import numpy as np
@@ -17,8 +24,8 @@ import pytest
 import torch
 
 from oracle import slate_oracle as O
-from tests.gpu_util import dims_from_cfg, load_params, log, relerr
-from tests.test_gpu_slate import compare_forward, dev_noise
+from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, mask_matched_fp64_grads, relerr
+from tests.test_gpu_slate import GRAD_TOL, compare_forward, dev_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -31,30 +38,55 @@ def _summ(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
 
 
+class _ReluRecorder:
+    """records the mask of every F.relu call of an oracle run, in call order"""
+
+    def __init__(self):
+        self.masks = []
+        self._orig = torch.nn.functional.relu
+
+    def __enter__(self):
+        def relu(x, inplace=False):
+            self.masks.append((x > 0).detach())
+            return self._orig(x)
+        torch.nn.functional.relu = relu
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.functional.relu = self._orig
+
+
 def run_oracles(cfg, P, obs, noise, step):
-    """fp32 oracle (the reference's arithmetic) and an fp64 run of the same restatement"""
+    """fp32 oracle (the reference's arithmetic) and an fp64 run of the same restatement; returns the number of ReLU masks that differ"""
     t32 = O.OracleTrainer(cfg, P)
-    r32 = t32.loss_and_grads(obs, noise, step, None)
+    with _ReluRecorder() as r32m:
+        r32 = t32.loss_and_grads(obs, noise, step, None)
     P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
     t64 = O.OracleTrainer(cfg, P64)
-    t64.loss_and_grads(obs.double(), {k: v.double() for k, v in noise.items()}, step, None)
+    with _ReluRecorder() as r64m:
+        t64.loss_and_grads(obs.double(), {k: v.double() for k, v in noise.items()}, step, None)
+    assert len(r32m.masks) == len(r64m.masks)
+    flips = [int((a != b).sum()) for a, b in zip(r32m.masks, r64m.masks)]
+    total = sum(int(a.numel()) for a in r64m.masks)
+    log(f"   ReLU masks fp32 oracle vs fp64 oracle: {sum(flips)} flips in {total} units; per site (non-zero): " +
+        ", ".join(f"#{i}:{f}" for i, f in enumerate(flips) if f))
     return t32, r32, t64
 
 
 def grade_gradients(tag, eng, t32, t64):
     gmax = max(t64.P[p.name].grad.abs().max().item() for p in eng.params)
-    rows, bad = [], []
+    rows = []
     for p in eng.params:
         ref = t64.P[p.name].grad.reshape(p.shape)
-        e_hip = relerr(eng.view(eng.flat_g, p), ref, floor=1e-5 * gmax)
-        e_o32 = relerr(t32.P[p.name].grad.reshape(p.shape), ref, floor=1e-5 * gmax)
+        e_hip = relerr(eng.view(eng.flat_g, p), ref, floor=grad_floor(p.name, gmax))
+        e_o32 = relerr(t32.P[p.name].grad.reshape(p.shape), ref, floor=grad_floor(p.name, gmax))
         rows.append((e_hip, e_o32, p.name))
-        if e_hip > max(GRAD_FACTOR * e_o32, GRAD_FLOOR):
-            bad.append((p.name, e_hip, e_o32))
+    worst_o32 = max(r[1] for r in rows)
+    bad = [(n, a, b) for a, b, n in rows if a > max(GRAD_FACTOR * b, GRAD_FLOOR, worst_o32)]
     rows.sort(reverse=True)
-    log(f"[{tag}] gradients vs fp64 oracle: worst HIP {rows[0][0]:.2e} (fp32 oracle on that tensor {rows[0][1]:.2e}); worst ratio "
-        f"{max(r[0] / max(r[1], 1e-9) for r in rows if r[0] > GRAD_FLOOR) if any(r[0] > GRAD_FLOOR for r in rows) else 0:.2f}; top: "
-        + "; ".join(f"{n} {a:.1e}/{b:.1e}" for a, b, n in rows[:6]))
+    med = sorted(r[0] for r in rows)[len(rows) // 2]
+    log(f"[{tag}] gradients vs fp64 oracle over {len(rows)} tensors: HIP worst {rows[0][0]:.2e} median {med:.2e}; fp32 oracle worst {worst_o32:.2e} median "
+        f"{sorted(r[1] for r in rows)[len(rows) // 2]:.2e}; top (HIP/fp32-oracle): " + "; ".join(f"{n} {a:.1e}/{b:.1e}" for a, b, n in rows[:6]))
     assert not bad, bad[:6]
 
 
@@ -161,7 +193,15 @@ def test_full_config_against_oracle(tag, over, B):
         assert errs[k] < 1e-4, (k, errs[k])
     eng.backward()
     torch.cuda.synchronize()
-    grade_gradients(tag, eng, t32, t64)
+    grade_gradients(tag, eng, t32, t64)          # as is: HIP no further from fp64 than fp32 arithmetic gets on this input
+    # with the ReLU decisions of the HIP forward held fixed in the fp64 run: tight, per tensor
+    t64m, fr = mask_matched_fp64_grads(cfg, P, obs, noise, step, hip_relu_masks(eng, cfg, B))
+    gmax = max(t64m.P[p.name].grad.abs().max().item() for p in eng.params)
+    rows = sorted(((relerr(eng.view(eng.flat_g, p), t64m.P[p.name].grad.reshape(p.shape), floor=grad_floor(p.name, gmax)), p.name) for p in eng.params), reverse=True)
+    log(f"[{tag}] gradients vs mask-matched fp64 oracle: worst {rows[0][0]:.2e} ({fr.flips} of {fr.units} ReLU decisions of the HIP forward differ from "
+        f"fp64's own" + (f", largest |pre-activation| among them {max(fr.min_flipped):.1e}" if fr.flips else "") + "); top: "
+        + "; ".join(f"{n}={e:.1e}" for e, n in rows[:5]))
+    assert rows[0][0] < GRAD_TOL, rows[:5]
 
 
 def test_config_z_batch_additivity():

@@ -1,15 +1,19 @@
 """Whole-path parity: the HIP SLATE step (through the C ABI) against the CPU oracle on identical weights,
 inputs and injected noise.  Stated tolerances (fp32, different summation order):
-  loss terms 1e-5 rel; activations 1e-4 rel (max-norm); gradients 1e-3 rel to each tensor's max
-  (floored at 1e-5 x the largest gradient); parameters after Adam steps 1e-4 rel."""
+  loss terms 1e-5 rel; activations 1e-4 rel (max-norm); parameters after Adam steps 1e-5 rel;
+  gradients GRAD_TOL of each tensor's max (floored at 1e-5 x the largest gradient) against an fp64 run of the oracle that uses the
+  ReLU decisions of the HIP forward (tests/gpu_util.py: a pre-activation inside rounding noise of zero may fall either way in any
+  fp32 evaluation, and one such flip moves a weight gradient by ~1/N of its max; holding the masks fixed removes that coin toss
+  and lets the tolerance be tight.  GRAD_TOL = 3x the worst value measured over all cases of this file and test_gpu_fullconfig.py)."""
 import numpy as np
 import pytest
 import torch
 
-from tests.gpu_util import dims_from_cfg, load_params, log, relerr
+from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, mask_matched_fp64_grads, relerr
 from oracle import slate_oracle as O
 
 pytestmark = pytest.mark.gpu
+GRAD_TOL = 5e-5      # worst measured: 2.0e-5 (config Z, self-attention q/k projections, T = 4096); <= 9e-6 in every other case
 
 SMALL = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2)
 MID = dict(obs_size=32, vocab_size=512, num_slots=5, num_iterations=2, num_dec_blocks=2)
@@ -70,16 +74,38 @@ def compare_forward(tag, eng, cfg, res, B):
     return errs
 
 
-def compare_grads(tag, eng, trainer):
-    gmax = max(trainer.P[p.name].grad.abs().max().item() for p in eng.params)
-    worst, rows = 0.0, []
+def compare_grads(tag, eng, trainer, cfg=None, P=None, obs=None, noise=None, step=0, drop_masks=None):
+    """every parameter gradient of the HIP backward against (a) the fp32 oracle's autograd (logged) and (b) an fp64 run of the oracle
+    under the HIP forward's ReLU decisions (graded: returns its worst per-tensor error)"""
+    names = [p.name for p in eng.params if trainer.P[p.name].grad is not None]
+    gmax = max(trainer.P[n].grad.abs().max().item() for n in names)
+    worst32, rows32 = 0.0, []
     for p in eng.params:
         ref = trainer.P[p.name].grad
-        e = relerr(eng.view(eng.flat_g, p), ref.reshape(p.shape), floor=1e-5 * gmax)
+        if ref is None:
+            assert float(eng.view(eng.flat_g, p).abs().max()) == 0.0, p.name          # no gradient in this mode
+            continue
+        e = relerr(eng.view(eng.flat_g, p), ref.reshape(p.shape), floor=grad_floor(p.name, gmax))
+        rows32.append((e, p.name))
+        worst32 = max(worst32, e)
+    rows32.sort(reverse=True)
+    if cfg is None:
+        log(f"[{tag}] grads vs fp32 oracle: worst {worst32:.2e}; top: " + "; ".join(f"{n}={e:.1e}" for e, n in rows32[:6]))
+        return worst32, rows32
+    B = obs.shape[0]
+    t64, fr = mask_matched_fp64_grads(cfg, P, obs, noise, step, hip_relu_masks(eng, cfg, B), drop_masks)
+    worst, rows = 0.0, []
+    for p in eng.params:
+        ref = t64.P[p.name].grad
+        if ref is None:
+            continue
+        e = relerr(eng.view(eng.flat_g, p), ref.reshape(p.shape), floor=grad_floor(p.name, gmax))
         rows.append((e, p.name))
         worst = max(worst, e)
     rows.sort(reverse=True)
-    log(f"[{tag}] grads: worst {worst:.2e}; top: " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:8]))
+    log(f"[{tag}] grads vs mask-matched fp64 oracle: worst {worst:.2e} ({fr.flips} of {fr.units} ReLU decisions differ from fp64's own"
+        + (f", largest |pre-activation| among them {max(fr.min_flipped):.1e}" if fr.flips else "") + f"); vs fp32 oracle as is: worst {worst32:.2e} "
+        f"({rows32[0][1]}); top: " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:5]))
     return worst, rows
 
 
@@ -109,8 +135,8 @@ def test_forward_backward_eval(tag, over, B):
         assert errs[k] < 1e-4, (k, errs[k])
     eng.backward()
     torch.cuda.synchronize()
-    worst, rows = compare_grads(tag, eng, tr)
-    assert worst < 1e-3, rows[:5]
+    worst, rows = compare_grads(tag, eng, tr, cfg, P, obs, noise, step)
+    assert worst < GRAD_TOL, rows[:5]
 
 
 @pytest.mark.parametrize("over", [SMALL, LONG])
@@ -135,8 +161,8 @@ def test_train_mode_dropout_parity(over):
     e = abs(m[2].item() - res["loss"].item()) / abs(res["loss"].item())
     log(f"[dropout] loss rel err {e:.2e} keep-rate {keep:.4f}")
     assert e < 1e-5
-    worst, rows = compare_grads("dropout", eng, tr)
-    assert worst < 1e-3, rows[:5]
+    worst, rows = compare_grads("dropout", eng, tr, cfg, P, obs, noise, 0, masks)
+    assert worst < GRAD_TOL, rows[:5]
 
 
 def test_update_steps_match_oracle():
@@ -161,7 +187,7 @@ def test_update_steps_match_oracle():
         en = abs(m[3].item() - float(res["norm"])) / float(res["norm"])
         worst = max(relerr(eng.view(eng.flat_p, p), tr.P[p.name].reshape(p.shape)) for p in eng.params)
         log(f"[update] step {step}: loss err {el:.2e} norm err {en:.2e} worst param err {worst:.2e}")
-        assert el < 2e-5 and en < 1e-3 and worst < 1e-4
+        assert el < 1e-5 and en < 1e-5 and worst < 1e-5
 
 
 def test_encode_matches_forward_slots():
@@ -236,26 +262,15 @@ def test_broadcast_decoder_config_matches_oracle(tag, over, B):
         el = abs(m[2].item() - res["loss"].item()) / abs(res["loss"].item())
         er = relerr(eng.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2), res["recon_bc"])
         es = relerr(eng.tensor("slots", (B, K, D)), res["slots"])
-        gmax = max(tr2.P[p.name].grad.abs().max().item() for p in eng.params if tr2.P[p.name].grad is not None)
-        worst, rows = 0.0, []
-        for p in eng.params:
-            ref = tr2.P[p.name].grad
-            got = eng.view(eng.flat_g, p)
-            if ref is None:
-                assert float(got.abs().max()) == 0.0, p.name          # no gradient in this mode
-                continue
-            e = relerr(got, ref.reshape(p.shape), floor=1e-5 * gmax)
-            rows.append((e, p.name))
-            worst = max(worst, e)
-        rows.sort(reverse=True)
-        log(f"[{tag}] step {step}: loss {el:.2e} recon {er:.2e} slots {es:.2e} grads worst {worst:.2e}; top " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:5]))
-        assert el < 1e-5 and er < 1e-4 and es < 1e-4 and worst < 1e-3, rows[:5]
+        worst, rows = compare_grads(f"{tag} step {step}", eng, tr2, cfg, {n: p.detach() for n, p in tr.P.items()}, obs, noise, step)
+        log(f"[{tag}] step {step}: loss {el:.2e} recon {er:.2e} slots {es:.2e}")
+        assert el < 1e-5 and er < 1e-4 and es < 1e-4 and worst < GRAD_TOL, rows[:5]
         tr.update(obs, noise, step, None)
         eng.clip_adam(lrs, cfg.clip)
         torch.cuda.synchronize()
         wp = max(relerr(eng.view(eng.flat_p, p), tr.P[p.name].reshape(p.shape)) for p in eng.params)
         log(f"[{tag}] step {step}: worst param err after update {wp:.2e}")
-        assert wp < 1e-4
+        assert wp < 1e-5
 
 
 def test_autoregressive_generation_matches_oracle():
