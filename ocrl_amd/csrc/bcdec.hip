@@ -92,8 +92,9 @@ __global__ void bc_layer1_kernel(const float* __restrict__ P1, const float* __re
                                                         fmaxf(p.z + t.z + b.z, 0.f), fmaxf(p.w + t.w + b.w, 0.f));
 }
 
-// dT[bk][cls][co] += sum over the pixels of row y in each column class of g[bk][y][x][co]   (one block per (bk, y))
-__global__ __launch_bounds__(256) void bc_layer1_bwd_kernel(const float* __restrict__ g, float* __restrict__ dT, int S) {
+// rowpart[bk][y][k][co] = sum over the pixels of row y in column class k of g[bk][y][x][co]   (one block per (bk, y));
+// bc_layer1_reduce_kernel then sums the rows of each row class in row order (no float atomics: bitwise reproducible)
+__global__ __launch_bounds__(256) void bc_layer1_bwd_kernel(const float* __restrict__ g, float* __restrict__ rowpart, int S) {
     __shared__ float red[4][5][64];
     const int y = blockIdx.x % S;
     const long long bk = blockIdx.x / S;
@@ -110,10 +111,21 @@ __global__ __launch_bounds__(256) void bc_layer1_bwd_kernel(const float* __restr
     for (int k = 0; k < 5; ++k) red[xl][k][co] = a[k];
     __syncthreads();
     if (xl == 0) {
-        const int rc = bc_class(y, S);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) atomicAdd(&dT[(bk * 25 + rc * 5 + k) * 64 + co], red[0][k][co] + red[1][k][co] + red[2][k][co] + red[3][k][co]);
+        for (int k = 0; k < 5; ++k) rowpart[((bk * S + y) * 5 + k) * 64 + co] = (red[0][k][co] + red[1][k][co]) + (red[2][k][co] + red[3][k][co]);
     }
+}
+// dT[bk][rc*5+k][co] = sum over the rows y of row class rc of rowpart[bk][y][k][co]
+__global__ void bc_layer1_reduce_kernel(const float* __restrict__ rowpart, float* __restrict__ dT, long long n, int S) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [BK][25][64]
+    if (i >= n) return;
+    const int co = i & 63, cls = (i >> 6) % 25;
+    const long long bk = i / (25 * 64);
+    const int rc = cls / 5, k = cls - rc * 5;
+    const int y0 = rc < 2 ? rc : (rc == 2 ? 2 : S - 2 + (rc - 3)), y1 = rc == 2 ? S - 2 : y0 + 1;
+    float a = 0.f;
+    for (int y = y0; y < y1; ++y) a += rowpart[((bk * S + y) * 5 + k) * 64 + co];
+    dT[i] = a;
 }
 
 // dWc[tap][co][j] = sum_{y,x : tap inside} G[y][x][co] * (grid_j(y+dy, x+dx) | 1)     (one block per tap, G = sum over bk)
@@ -416,9 +428,15 @@ int bc_layer1_launch(const float* P1, const float* Tc, const float* b1, float* c
     OCRL_CHECK_LAUNCH("bc_layer1");
     return 0;
 }
-int bc_layer1_bwd_launch(const float* g, float* dT, int BK, int S, hipStream_t st) {
-    hipLaunchKernelGGL(bc_layer1_bwd_kernel, dim3(BK * S), dim3(256), 0, st, g, dT, S);
+size_t bc_layer1_bwd_ws_floats(int BK, int S) { return (size_t)BK * S * 5 * 64; }
+// dT [BK][25][64] is written (not accumulated); ws: bc_layer1_bwd_ws_floats() floats of scratch
+int bc_layer1_bwd_launch(const float* g, float* dT, int BK, int S, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(S >= 5 && ws && ws_floats >= bc_layer1_bwd_ws_floats(BK, S), "bc_layer1_bwd: S < 5 or scratch too small");
+    hipLaunchKernelGGL(bc_layer1_bwd_kernel, dim3(BK * S), dim3(256), 0, st, g, ws, S);
     OCRL_CHECK_LAUNCH("bc_layer1_bwd");
+    const long long n = (long long)BK * 25 * 64;
+    hipLaunchKernelGGL(bc_layer1_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ws, dT, n, S);
+    OCRL_CHECK_LAUNCH("bc_layer1_reduce");
     return 0;
 }
 int bc_posconv_bwd_launch(const float* G, float* dWc, int S, hipStream_t st) {

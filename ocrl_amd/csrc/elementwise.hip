@@ -452,9 +452,19 @@ __global__ void embed_fwd_kernel(const int* __restrict__ tokens, const float* __
     *reinterpret_cast<float4*>(out + i * 4) = v;
 }
 
-// g <- dropout-backward(g) in place; ddict[tok] += g (atomics).  dpe/dbos come from a column sum over b.
-__global__ void embed_bwd_kernel(float* __restrict__ g, const int* __restrict__ tokens, float* __restrict__ ddict, int B, int T,
-                                 int d, float p, unsigned long long seed) {
+// g <- dropout-backward(g) in place; ddict[tok] += g.  The scatter-add over the positions that share a token is order-free and yet
+// bitwise reproducible: every contribution is converted to 64-bit fixed point (scale = 2^42 / 2^ceil(log2 max|g|), read from `amax`,
+// so up to 2^19 largest-magnitude terms cannot overflow) and added with integer atomics, which are associative.  Resolution 2^-42 of
+// the largest element (fp32 carries 2^-24 of each element): elements above 4e-6 x the maximum keep every fp32 bit.
+// embed_fix_to_float_kernel converts the [V,d] accumulator back.  dpe/dbos come from a column sum over b.
+__device__ __forceinline__ float embed_fix_scale(float amax) {
+    if (!(amax > 0.f)) return 0.f;
+    int e;
+    frexpf(amax, &e);                     // amax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 42 - e);          // |g| * scale < 2^42
+}
+__global__ void embed_bwd_kernel(float* __restrict__ g, const int* __restrict__ tokens, unsigned long long* __restrict__ acc,
+                                 const float* __restrict__ amax, int B, int T, int d, float p, unsigned long long seed) {
     const int d4 = d / 4;
     const long long n = (long long)B * T * d4;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -476,9 +486,20 @@ __global__ void embed_bwd_kernel(float* __restrict__ g, const int* __restrict__ 
         *reinterpret_cast<float4*>(g + i * 4) = v;
     }
     if (t > 0) {
-        float* dst = ddict + (size_t)tokens[b * T + t - 1] * d + c4 * 4;
-        atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        // amax is the maximum before the dropout rescale (x 1/(1-p) <= 2 for p <= 0.5: one bit of the head-room)
+        const double s = (double)embed_fix_scale(amax[0]) * 0.5;
+        unsigned long long* dst = acc + (size_t)tokens[b * T + t - 1] * d + c4 * 4;
+        atomicAdd(dst + 0, (unsigned long long)__double2ll_rn((double)v.x * s));
+        atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)v.y * s));
+        atomicAdd(dst + 2, (unsigned long long)__double2ll_rn((double)v.z * s));
+        atomicAdd(dst + 3, (unsigned long long)__double2ll_rn((double)v.w * s));
     }
+}
+__global__ void embed_fix_to_float_kernel(const unsigned long long* __restrict__ acc, const float* __restrict__ amax, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double s = (double)embed_fix_scale(amax[0]) * 0.5;
+    out[i] = s > 0.0 ? (float)((double)(long long)acc[i] / s) : 0.f;
 }
 
 // y = x * keep/(1-p) for the dropout site (n % 4 == 0); index = element offset
@@ -508,6 +529,7 @@ __global__ void dropout_mask_kernel(float* __restrict__ y, long long n, float p,
 // Q [B,T,d] (projected, unscaled), Km/Vm [B,K,d], heads h, dh = d/h (<= 64).  One thread per (b,head,q).
 // P [B,h,T,K] = softmax (pre-dropout) is saved for the backward.
 // MAXK (8 or 16) is the compile-time slot capacity: per-slot values live in registers.
+#define RC_(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 #define CA_MAXDH 64
 template <int CA_MAXK>
 __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Km,
@@ -583,17 +605,20 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
         if (c < dh) *reinterpret_cast<float4*>(op + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
 }
 
-// backward: dQ [B,T,d] written; dKm/dVm [B,K,d] accumulated with one atomic per (wave, slot, channel)
-// (must be zeroed by the caller).  The per-query outer products are reduced over the 64 queries of a wave
-// through a wave-private LDS staging tile (queries x (K + dh)), not through contended atomics.
+// backward: dQ [B,T,d] written; the slot-side gradients leave each workgroup as one partial [2][K*dh] (dV, dK) in `part`,
+// summed over the query blocks in a fixed order by cross_attn_reduce_kernel (no float atomics: bitwise reproducible).  The
+// per-query outer products are reduced over the 64 queries of a wave through a wave-private LDS staging tile (queries x (K + dh)),
+// then over the four waves through LDS.
 template <int CA_MAXK>
 __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ Q,
                                                              const float* __restrict__ Km, const float* __restrict__ Vm,
                                                              const float* __restrict__ P, float* __restrict__ dQ,
-                                                             float* __restrict__ dKm, float* __restrict__ dVm, int T, int K, int d,
+                                                             float* __restrict__ part, int T, int K, int d,
                                                              int h, float p, unsigned long long seed, unsigned site) {
     extern __shared__ float sm[];   // Ks [K][dh], Vs [K][dh], stage [4][64][CA_SW]
     constexpr int CA_SW = CA_MAXK + CA_MAXDH + 1;
+    constexpr int NACC = CA_MAXK * CA_MAXDH / 64;          // slot-side outputs per lane
+    float* mypart = part + (size_t)blockIdx.x * 2 * K * (d / h);
     const int dh = d / h;
     const int nqb = (T + 255) / 256;
     int bid = blockIdx.x;
@@ -658,11 +683,24 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     for (int c = 0; c < CA_MAXDH; ++c)
         if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = go[c];
     __syncthreads();
-    for (int o = lane; o < K * dh; o += 64) {
-        const int k = o / dh, c = o - k * dh;
+    float av[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        const int o = lane + 64 * i;
         float a = 0.f;
-        for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
-        atomicAdd(&dVm[(b * K + k) * d + hd * dh + c], a);
+        if (o < K * dh) {
+            const int k = o / dh, c = o - k * dh;
+            for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
+        }
+        av[i] = a;
+    }
+    __syncthreads();                                       // every wave is done reading its staging tile
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) stg[lane + 64 * i] = av[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < K * dh; o += 256) {
+        const float* r = sm + 2 * K * dh + o;
+        mypart[o] = (r[0] + r[64 * CA_SW]) + (r[2 * 64 * CA_SW] + r[3 * 64 * CA_SW]);
     }
     __syncthreads();
     // ---- dS, dQ, and dK[k][c] += sum_q ds[q][k] * q'[q][c]
@@ -683,11 +721,23 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     for (int c = 0; c < CA_MAXDH; ++c)
         if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = qv[c];
     __syncthreads();
-    for (int o = lane; o < K * dh; o += 64) {
-        const int k = o / dh, c = o - k * dh;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        const int o = lane + 64 * i;
         float a = 0.f;
-        for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
-        atomicAdd(&dKm[(b * K + k) * d + hd * dh + c], a);
+        if (o < K * dh) {
+            const int k = o / dh, c = o - k * dh;
+            for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
+        }
+        av[i] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) stg[lane + 64 * i] = av[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < K * dh; o += 256) {
+        const float* r = sm + 2 * K * dh + o;
+        mypart[K * dh + o] = (r[0] + r[64 * CA_SW]) + (r[2 * 64 * CA_SW] + r[3 * 64 * CA_SW]);
     }
     if (act) {
         float* dqp = dQ + (b * T + q) * d + hd * dh;
@@ -960,10 +1010,21 @@ int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, con
     OCRL_CHECK_LAUNCH("embed_fwd");
     return 0;
 }
-int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int d, float p, unsigned long long seed, hipStream_t st) {
-    const long long n = (long long)B * T * (d / 4);
-    hipLaunchKernelGGL(embed_bwd_kernel, GRID1D(n), 0, st, g, tokens, ddict, B, T, d, p, seed);
+size_t embed_bwd_ws_floats(int V, int d) { return 1024 + 16 + (size_t)V * d * 2; }
+// ddict [V,d] is written (no pre-zeroing needed); ws: embed_bwd_ws_floats() floats, 8-byte aligned
+int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int V, int d, float p, unsigned long long seed, float* ws,
+                     size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(p <= 0.5f && (long long)B * T <= (1ll << 19), "embed_bwd: dropout > 0.5 or more than 2^19 positions (fixed-point head-room)");
+    OCRL_REQUIRE(ws && ws_floats >= embed_bwd_ws_floats(V, d) && ((uintptr_t)ws & 7) == 0, "embed_bwd: scratch too small or misaligned");
+    float* amax = ws + 1024;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(ws + 1040);
+    const long long n = (long long)B * T * (d / 4), nv = (long long)V * d;
+    RC_(absmax_launch(g, (long long)B * T * d, amax, ws, 1024, st));
+    OCRL_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (size_t)nv, st));
+    hipLaunchKernelGGL(embed_bwd_kernel, GRID1D(n), 0, st, g, tokens, acc, amax, B, T, d, p, seed);
     OCRL_CHECK_LAUNCH("embed_bwd");
+    hipLaunchKernelGGL(embed_fix_to_float_kernel, GRID1D(nv), 0, st, acc, amax, ddict, nv);
+    OCRL_CHECK_LAUNCH("embed_fix_to_float");
     return 0;
 }
 int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st) {
@@ -986,9 +1047,27 @@ int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, floa
     OCRL_CHECK_LAUNCH("cross_attn_fwd");
     return 0;
 }
+// dKm / dVm [B,K,d] = sum over the query blocks of the per-workgroup partials, in block order
+__global__ void cross_attn_reduce_kernel(const float* __restrict__ part, float* __restrict__ dKm, float* __restrict__ dVm, long long n, int nqb,
+                                         int K, int d, int h) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [B][K][d]
+    if (i >= n) return;
+    const int dh = d / h;
+    const int col = i % d, k = (i / d) % K;
+    const long long b = i / ((long long)d * K);
+    const int hd = col / dh, c = col - hd * dh;
+    const float* src = part + ((b * h + hd) * nqb) * 2 * K * dh + k * dh + c;
+    float av = 0.f, ak = 0.f;
+    for (int q = 0; q < nqb; ++q) { av += src[(size_t)q * 2 * K * dh]; ak += src[(size_t)q * 2 * K * dh + K * dh]; }
+    dVm[i] = av;
+    dKm[i] = ak;
+}
+
+size_t cross_attn_bwd_ws_floats(int B, int T, int K, int d, int h) { return (size_t)B * h * cdiv(T, 256) * 2 * K * (d / h); }
+
 template <int MAXK>
 static int cross_attn_bwd_launch_k(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
-                                   int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+                                   int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, float* part, hipStream_t st) {
     constexpr int SW = MAXK + CA_MAXDH + 1;
     const int grid = B * h * cdiv(T, 256);
     static bool attr_set = false;
@@ -997,15 +1076,21 @@ static int cross_attn_bwd_launch_k(const float* dO, const float* Q, const float*
                                      (2 * MAXK * CA_MAXDH + 4 * 64 * SW) * 4));
         attr_set = true;
     }
-    hipLaunchKernelGGL(cross_attn_bwd_kernel<MAXK>, dim3(grid), dim3(256), (2 * K * (d / h) + 4 * 64 * SW) * 4, st, dO, Q, Km, Vm, P, dQ, dKm, dVm, T, K, d, h, p, seed, site);
+    hipLaunchKernelGGL(cross_attn_bwd_kernel<MAXK>, dim3(grid), dim3(256), (2 * K * (d / h) + 4 * 64 * SW) * 4, st, dO, Q, Km, Vm, P, dQ, part, T, K, d, h, p, seed, site);
     OCRL_CHECK_LAUNCH("cross_attn_bwd");
+    const long long n = (long long)B * K * d;
+    hipLaunchKernelGGL(cross_attn_reduce_kernel, GRID1D(n), 0, st, part, dKm, dVm, n, cdiv(T, 256), K, d, h);
+    OCRL_CHECK_LAUNCH("cross_attn_reduce");
     return 0;
 }
+// dKm / dVm are written (not accumulated); part: cross_attn_bwd_ws_floats() floats of scratch
 int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
-                          int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st) {
+                          int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, float* part, size_t part_floats,
+                          hipStream_t st) {
     OCRL_REQUIRE(K >= 1 && K <= 16 && d % h == 0 && (d / h) <= CA_MAXDH && (d / h) % 4 == 0, "cross_attn: unsupported K=%d d=%d h=%d", K, d, h);
-    if (K <= 8) return cross_attn_bwd_launch_k<8>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, st);
-    return cross_attn_bwd_launch_k<16>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, st);
+    OCRL_REQUIRE(part && part_floats >= cross_attn_bwd_ws_floats(B, T, K, d, h), "cross_attn_bwd: scratch too small");
+    if (K <= 8) return cross_attn_bwd_launch_k<8>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, part, st);
+    return cross_attn_bwd_launch_k<16>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, part, st);
 }
 int fill_launch(float* x, long long n, float v, hipStream_t st) {
     hipLaunchKernelGGL(fill_kernel, GRID1D(n), 0, st, x, n, v);

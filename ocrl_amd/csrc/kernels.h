@@ -87,13 +87,17 @@ int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float 
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st);
 int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,
                      unsigned long long seed, hipStream_t st);
-int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int d, float p, unsigned long long seed, hipStream_t st);
+size_t embed_bwd_ws_floats(int V, int d);
+int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int V, int d, float p, unsigned long long seed, float* ws,
+                     size_t ws_floats, hipStream_t st);
 int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
 int dropout_mask_launch(float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
 int cross_attn_fwd_launch(const float* Q, const float* Km, const float* Vm, float* O, float* P, int B, int T, int K, int d, int h, float p,
                           unsigned long long seed, unsigned site, hipStream_t st);
+size_t cross_attn_bwd_ws_floats(int B, int T, int K, int d, int h);
 int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
-                          int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, hipStream_t st);
+                          int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, float* part, size_t part_floats,
+                          hipStream_t st);
 int fill_launch(float* x, long long n, float v, hipStream_t st);
 int axpy_launch(const float* x, float* y, long long n, float a, hipStream_t st);
 int posmap_launch(const float* Wpos, const float* bpos, float* out, int S, int C, hipStream_t st);
@@ -194,7 +198,8 @@ int bc_compose_launch(const float* W1, const float* Wpos, const float* bpos, flo
 int bc_posconv_launch(const float* Wc, float* P1, int S, hipStream_t st);
 int bc_class_sum_launch(const float* in, float* out, int BK, int forward, hipStream_t st);
 int bc_layer1_launch(const float* P1, const float* Tc, const float* b1, float* c1, int BK, int S, hipStream_t st);
-int bc_layer1_bwd_launch(const float* g, float* dT, int BK, int S, hipStream_t st);
+size_t bc_layer1_bwd_ws_floats(int BK, int S);
+int bc_layer1_bwd_launch(const float* g, float* dT, int BK, int S, float* ws, size_t ws_floats, hipStream_t st);
 int bc_posconv_bwd_launch(const float* G, float* dWc, int S, hipStream_t st);
 int bc_compose_bwd_launch(const float* W1, const float* Wpos, const float* bpos, const float* dWc, const float* dW1r, float* dW1,
                           float* dWpos, float* dbpos, int D, hipStream_t st);

@@ -136,6 +136,10 @@ void SlateModel::layout_workspace(bool commit) {
         if (sk > need) need = sk;
         size_t cs = (size_t)N * C * 8 + (size_t)T * d * 8 + (1 << 20);   // column-sum partials (pos map / pe)
         if (cs > need) need = cs;
+        if (cfg.use_bcdec && bc_layer1_bwd_ws_floats((int)(B * K), S) > need) need = bc_layer1_bwd_ws_floats((int)(B * K), S);
+        const size_t ca = cross_attn_bwd_ws_floats((int)B, T, K, d, NH), eb = embed_bwd_ws_floats(V, d);
+        if (ca > need) need = ca;
+        if (eb > need) need = eb;
         scratch_floats_ = need + (1 << 20);
     }
     scratch_ = carve(nullptr, scratch_floats_);
@@ -587,9 +591,7 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         dr.site = site + 3;
         RC(lin_bwd_w(gx_, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st, dr));
         RC(lin_bwd_x(gx_, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st, dr));   // d cao
-        RC(fill_launch(gck_, BK * d, 0.f, st));
-        RC(fill_launch(gcv_, BK * d, 0.f, st));
-        RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, gt2_, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, st));   // gt2 = d cq
+        RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, gt2_, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, scratch_, scratch_floats_, st));   // gt2 = d cq
         RC(lin_bwd_w(gt2_, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
         RC(lin_bwd_x(gt2_, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
         RC(lin_bwd_w(gck_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, BK, d, d, 1.f, st));
@@ -622,9 +624,8 @@ int SlateModel::bwd_decoder(hipStream_t st) {
                                     G(pre + "self_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         }
     }
-    // ---- embedding: gx_ = d emb (after dropout);  dictionary (atomics), pe / bos (sum over the batch)
-    RC(fill_launch(G("_dict.dictionary.weight"), (long long)V * d, 0.f, st));
-    RC(embed_bwd_launch(gx_, tokens_, G("_dict.dictionary.weight"), B, T, d, p, last_.seed, st));
+    // ---- embedding: gx_ = d emb (after dropout);  dictionary (order-free exact scatter-add), pe / bos (sum over the batch)
+    RC(embed_bwd_launch(gx_, tokens_, G("_dict.dictionary.weight"), B, T, V, d, p, last_.seed, scratch_, scratch_floats_, st));
     RC(fill_launch(G("_z_pos.pe"), (long long)(T + 1) * d, 0.f, st));
     RC(colsum_launch(gx_, (long long)T * d, G("_z_pos.pe"), B, T * d, 0, 1.f, scratch_, scratch_floats_, st));
     RC(copy_launch(G("_z_pos.pe"), G("_bos_token._bos_token"), d, st));
@@ -845,8 +846,7 @@ int SlateModel::bwd_bcdec(hipStream_t st) {
     RC(conv_layer_wgrad(bc_c1_, bc_gB_, G("_dec._decoder.1.m.weight"), G("_dec._decoder.1.m.bias"), BK, S, S, 5, 64, 64, st));
     RC(conv_layer_fwd(bc_gB_, bc_pkb_[0], nullptr, bc_gA_, BK, S, S, 5, 64, 0, nullptr, bc_c1_, st));               // gA = d c1 (pre-relu)
     // first layer through the shortcut
-    RC(fill_launch(bc_dT_, (long long)BK * 1600, 0.f, st));
-    RC(bc_layer1_bwd_launch(bc_gA_, bc_dT_, BK, S, st));
+    RC(bc_layer1_bwd_launch(bc_gA_, bc_dT_, BK, S, scratch_, scratch_floats_, st));
     RC(colsum_launch(bc_dT_, 64, G("_dec._decoder.0.m.bias"), (long long)BK * 25, 64, 0, 1.f, scratch_, scratch_floats_, st));
     RC(bc_class_sum_launch(bc_dT_, bc_dM_, BK, 0, st));
     RC(lin_bwd_x(bc_dM_, 1600, bc_W1r_, gslots_, D, BK, 1600, D, nullptr, 0, nullptr, 0, st));                      // d slots

@@ -95,9 +95,11 @@ __device__ __noinline__ void ln_rows(const float* in, float* out, const float* _
         for (int c = lane; c < D; c += 64) out[j * D + c] = (in[j * D + c] - mu) * rs * g[c] + b[c];
     }
 }
-// dx[j] (+)= LN backward of rows; accumulates dgamma/dbeta (LDS, atomics)
+// dx[j] (+)= LN backward of rows; accumulates dgamma/dbeta into LDS accumulators.  The column sums over the rows run in a fixed
+// order (thread c adds rows 0..K-1), not as atomics: run-to-run bitwise reproducibility is the repo's race detector.  Block-uniform call.
 __device__ __noinline__ void ln_rows_bwd(const float* dy, const float* xin, float* dx, int accumulate, const float* __restrict__ g,
                                          float* dgam, float* dbet, int K, int D) {
+    __shared__ float s_mu[16], s_rs[16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int j = wv; j < K; j += nw) {
         float s = 0.f;
@@ -106,12 +108,11 @@ __device__ __noinline__ void ln_rows_bwd(const float* dy, const float* xin, floa
         float q = 0.f;
         for (int c = lane; c < D; c += 64) { const float d = xin[j * D + c] - mu; q += d * d; }
         const float rs = rsqrtf(wave_sum(q) / D + 1e-5f);
+        if (lane == 0) { s_mu[j] = mu; s_rs[j] = rs; }
         float s1 = 0.f, s2 = 0.f;
         for (int c = lane; c < D; c += 64) {
             const float xh = (xin[j * D + c] - mu) * rs;
             const float d = dy[j * D + c];
-            atomicAdd(&dgam[c], d * xh);
-            atomicAdd(&dbet[c], d);
             s1 += d * g[c];
             s2 += d * g[c] * xh;
         }
@@ -122,6 +123,17 @@ __device__ __noinline__ void ln_rows_bwd(const float* dy, const float* xin, floa
             const float v = rs * (dy[j * D + c] * g[c] - s1 - xh * s2);
             dx[j * D + c] = accumulate ? dx[j * D + c] + v : v;
         }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float ag = 0.f, ab = 0.f;
+        for (int j = 0; j < K; ++j) {
+            const float d = dy[j * D + c];
+            ag += d * (xin[j * D + c] - s_mu[j]) * s_rs[j];
+            ab += d;
+        }
+        dgam[c] += ag;
+        dbet[c] += ab;
     }
 }
 
