@@ -141,6 +141,43 @@ def timed_region(args, dev, dist, step_fn, prof_mask):
     return dt, list(ms), list(cnt), last
 
 
+def slot_attention_standalone(B, N, K, iters=10):
+    """the north-star kernel chain on its own (include/ocrl_hip.h ocrl_slot_attention_fwd/bwd, same code path as the model), timed with
+    HIP events around the streaming + slot-side launches only: inside the step its forward shares the GPU with the dVAE branch
+    (OCRL_OVERLAP), which stretches the in-situ figure"""
+    from ocrl_amd import _lib
+    L, p = _lib.lib(), _lib.ptr
+    D = H = 192
+    C, I = 64, 3
+    shp = [(C,), (C,), (D,), (D,), (D,), (D,), (D, D), (D, C), (D, C), (3 * D, D), (3 * D, D), (3 * D,), (3 * D,), (H, D), (H,), (D, H), (D,)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w = [(torch.randn(s, device="cuda", generator=g) / (s[-1] ** 0.5 if len(s) > 1 else 10.0) + (1.0 if len(s) == 1 and i in (0, 2, 4) else 0.0)) for i, s in enumerate(shp)]
+    gr = [torch.zeros_like(t) for t in w]
+    x = torch.randn(B, N, C, device="cuda", generator=g)
+    s0 = torch.randn(B, K, D, device="cuda", generator=g)
+    ds = torch.randn(B, K, D, device="cuda", generator=g)
+    slots, attn, dx, ds0 = torch.empty(B, K, D, device="cuda"), torch.empty(B, N, K, device="cuda"), torch.empty_like(x), torch.empty_like(s0)
+    nws = L.ocrl_slot_attention_ws_floats(B, K, D, H, I)
+    ws = torch.empty(nws, device="cuda")
+    arr = (ctypes.c_void_p * 17)(*[t.data_ptr() for t in w])
+    garr = (ctypes.c_void_p * 17)(*[t.data_ptr() for t in gr])
+
+    def once():
+        _lib.check(L.ocrl_slot_attention_fwd(p(x), p(s0), arr, p(slots), p(attn), B, N, K, D, H, I, p(ws), nws, None))
+        _lib.check(L.ocrl_slot_attention_bwd(p(x), p(ds), p(dx), p(ds0), garr, B, N, K, D, H, I, p(ws), nws, None))
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    L.ocrl_prof_enable((1 << 4) | (1 << 5))
+    for _ in range(iters):
+        once()
+    ms = (ctypes.c_double * 8)()
+    cnt = (ctypes.c_longlong * 8)()
+    _lib.check(L.ocrl_prof_collect(ctypes.byref(ms), ctypes.byref(cnt), 8))
+    L.ocrl_prof_enable(0)
+    return ms[4] / max(cnt[4], 1), ms[5] / max(cnt[5], 1)
+
+
 def mfma_roofline(kernel, flops_per_step, ms, cnt, steps, traffic):
     """achieved = algorithmic FLOPs of the family's launches in one step / their measured time in one step"""
     step_ms = ms / max(steps, 1)
@@ -306,12 +343,16 @@ def main():
     fwd_bytes = B * I * N * C * 4.0
     bwd_bytes = B * N * C * 4.0 * 8.0                 # x read 3x, d x written 3x and re-read 2x
     if cnt[4] and cnt[5]:
-        f_ms, b_ms = ms[4] / cnt[4], ms[5] / cnt[5]
-        out["slot_attention"] = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "fwd": {"avg_ms": round(f_ms, 4), "achieved": round(fwd_bytes / f_ms / 1e6, 1), "frac": round(fwd_bytes / f_ms / 1e6 / PEAK_HBM_GBS, 4)},
-                                 "bwd": {"avg_ms": round(b_ms, 4), "achieved": round(bwd_bytes / b_ms / 1e6, 1), "frac": round(bwd_bytes / b_ms / 1e6 / PEAK_HBM_GBS, 4)},
-                                 "note": "algorithmic bytes of the folded-projection form (12.6 MB/img forward at N=16384; the reference's materialised k|v "
-                                         "form would move 75.5 MB/img); MFMA-busy / HBM PMC counters for these kernels: profiles/r02_pmc_*"}
+        def leg(t_ms, nbytes):
+            return {"avg_ms": round(t_ms, 4), "achieved": round(nbytes / t_ms / 1e6, 1), "frac": round(nbytes / t_ms / 1e6 / PEAK_HBM_GBS, 4)}
+        sf_ms, sb_ms = slot_attention_standalone(B, N, K)
+        out["slot_attention"] = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "kernels": "sa_stream_fwd/bwd_kernel + sa_slot_fwd/bwd_kernel (one chain per call)",
+                                 "fwd": leg(sf_ms, fwd_bytes), "bwd": leg(sb_ms, bwd_bytes),
+                                 "in_step": {"fwd": leg(ms[4] / cnt[4], fwd_bytes), "bwd": leg(ms[5] / cnt[5], bwd_bytes),
+                                             "note": "inside the step the forward chain shares the GPU with the dVAE branch on the side stream (OCRL_OVERLAP)"},
+                                 "note": "algorithmic bytes of the folded-projection form (12.6 MB/img forward, 33.5 MB/img backward at N=16384; the reference's "
+                                         "materialised k|v form would move 75.5 MB/img forward); fwd / bwd = the chain on its own at the same shape, HIP events "
+                                         "around its launches; MFMA-busy / HBM PMC counters: profiles/r02_pmc_*"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec))
     print(json.dumps(out))

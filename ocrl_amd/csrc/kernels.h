@@ -154,13 +154,14 @@ struct SlotAttnArgs {
     float* dslots0 = nullptr;        // [B,K,D]
     float* grows = nullptr;          // [B*I*K, sa_grad_layout().ld]
     float* g_small = nullptr;        // [B][4D + 2C]: dgamma/dbeta of norm_slots, norm_mlp, norm_inputs
-    // split forward (several workgroups per image, one launch per iteration): exchange buffer of B * sa_xchg_floats() floats and
-    // B*I counters; both null = always the fused single-launch kernel
+    // pipelined form (streaming launches with several workgroups per image alternate with slot-side launches): per-image exchange
+    // buffer of B * sa_xchg_floats_host() floats and the partial-sum buffer of sa_parts_floats_host() floats; either null = the fused
+    // one-workgroup-per-image kernels
     float* xchg = nullptr;
-    int* counters = nullptr;
+    float* parts = nullptr;
 };
-#define SA_MAX_SPLIT 16
-size_t sa_xchg_floats_host(int K, int D);      // per image, sized for SA_MAX_SPLIT
+size_t sa_xchg_floats_host(int K, int D);      // per image
+size_t sa_parts_floats_host(int B, int K);
 int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st);
 
 // generic gather/transposing pack: entry e copies src[rows][cols] to dst + dst_off (transposed if requested)

@@ -15,7 +15,7 @@
 
 namespace {
 struct Lay {
-    size_t wts, save, grows, small, table, xchg, counters, scratch, scratch_floats, total;
+    size_t wts, save, grows, small, table, xchg, parts, scratch, scratch_floats, total;
 };
 Lay layout(int B, int K, int D, int H, int I) {
     const int C = 64;
@@ -31,7 +31,7 @@ Lay layout(int B, int K, int D, int H, int I) {
     l.small = take((size_t)B * (4 * D + 2 * C));
     l.table = take(64 * sizeof(PackEntry) / 4 + 64);
     l.xchg = take((size_t)B * sa_xchg_floats_host(K, D));
-    l.counters = take((size_t)B * I);
+    l.parts = take(sa_parts_floats_host(B, K));
     l.scratch_floats = (size_t)1024 * 3 * D * D / 4 + (1 << 18);
     l.scratch = take(l.scratch_floats);
     l.total = a;
@@ -92,7 +92,7 @@ int ocrl_slot_attention_fwd(const float* x, const float* slots0, const float* co
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x; a.slots0 = slots0; a.wts = ws + l.wts; a.slots = slots; a.attn = attn; a.save = ws + l.save;
-    a.xchg = ws + l.xchg; a.counters = reinterpret_cast<int*>(ws + l.counters);
+    a.xchg = ws + l.xchg; a.parts = ws + l.parts;
     return slot_attn_launch(a, 0, st);
 }
 
@@ -109,6 +109,7 @@ int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, floa
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x; a.wts = ws + l.wts; a.save = save; a.dslots = dslots; a.dx = dx; a.dslots0 = dslots0; a.grows = grows; a.g_small = small;
+    a.xchg = ws + l.xchg; a.parts = ws + l.parts;
     RC(slot_attn_launch(a, 1, st));
     const long long R = (long long)B * I * K;
     const size_t sf = l.scratch_floats;

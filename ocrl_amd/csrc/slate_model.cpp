@@ -159,7 +159,7 @@ void SlateModel::layout_workspace(bool commit) {
     sa_wts_ = carve(nullptr, wo.total);
     sa_small_ = carve(nullptr, B * (4 * D + 2 * C));
     sa_xchg_ = carve(nullptr, B * sa_xchg_floats_host(K, D));
-    sa_counters_ = reinterpret_cast<int*>(carve(nullptr, (size_t)B * I + 64));
+    sa_parts_ = carve(nullptr, sa_parts_floats_host((int)B, K));
     sa_pack_dev_ = reinterpret_cast<PackEntry*>(carve(nullptr, 64 * sizeof(PackEntry) / 4 + 64));
     for (int i = 0; i < 4; ++i) {
         const int cin = i == 0 ? 8 : 64;
@@ -236,12 +236,13 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     named_.clear();
     layout_workspace(true);
     if (!side_) {
-        // OCRL_OVERLAP (default 2): 2 = the dVAE branch is forked onto a side stream only at the slot-attention launches (one workgroup
-        // per image: half the CUs idle at B=128) and joined before the next 5x5 convolution, so the roofline kernel never shares the GPU
-        // (+1.8 % images/s, conv timings unchanged); 1 = whole dVAE branch beside encoder + decoder (+0.8 %, but per-kernel timings of
-        // both branches stop being comparable); 0 = single stream
+        // OCRL_OVERLAP (default 3): the dVAE branch (many short 64-wide products that do not fill the machine) runs on a side stream.
+        //   3 = forward beside the slot-attention launches, backward beside the transformer-decoder backward; joined before the 5x5
+        //       convolutions and the slot-attention backward, so those never share the GPU and their timings stay comparable
+        //   2 = forward and backward beside the slot-attention launches only (round 1's default, when slot attention left half the CUs idle)
+        //   1 = whole dVAE branch beside encoder + decoder (per-kernel timings of both branches stop being comparable); 0 = single stream
         const char* e = getenv("OCRL_OVERLAP");
-        overlap_mode_ = e ? atoi(e) : 2;
+        overlap_mode_ = e ? atoi(e) : 3;
         if (overlap_mode_) {
             OCRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
             OCRL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -396,14 +397,13 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, bool fork_dvae
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
-    a.xchg = sa_xchg_; a.counters = sa_counters_;
+    a.xchg = sa_xchg_; a.parts = sa_parts_;
     if (fork_dvae) {
         RC(fork_side(st));
         std::swap(scratch_, scratch2_);
         const int rc = fwd_dvae(in, side_);
         std::swap(scratch_, scratch2_);
         RC(rc);
-        a.xchg = nullptr; a.counters = nullptr;      // fused one-workgroup-per-image kernel: the dVAE kernels take the other CUs
     }
     RC(slot_attn_launch(a, 0, st));
     return 0;
@@ -507,7 +507,7 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
     }
     // the dVAE branch (tokens, reconstruction loss) and the CNN encoder + slot attention are independent until the decoder:
     // the dVAE runs on the side stream, filling the CUs the one-workgroup-per-image slot-attention kernel leaves idle
-    if (side_ && overlap_mode_ == 2) {
+    if (side_ && overlap_mode_ >= 2) {
         RC(fwd_encoder(in, st, true));       // forks the dVAE forward right before the slot-attention launch
         RC(join_side(st));
     } else if (side_) {
@@ -644,6 +644,7 @@ int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.wts = sa_wts_; a.save = sa_save_; a.dslots = gslots_; a.dx = gA_; a.dslots0 = gslots0_; a.grows = sa_grows_; a.g_small = sa_small_;
+    a.xchg = sa_xchg_; a.parts = sa_parts_;
     if (fork_dvae) {
         RC(fork_side(st));
         std::swap(scratch_, scratch2_);
@@ -764,6 +765,17 @@ int SlateModel::backward(hipStream_t st) {
     if (side_ && overlap_mode_ == 2) {
         RC(bwd_decoder(st));
         RC(bwd_encoder(st, true));           // forks the dVAE backward at the slot-attention launch, joins before the 5x5 convolutions
+    } else if (side_ && overlap_mode_ == 3) {
+        // the dVAE backward (many short 64-wide products) runs beside the transformer-decoder backward and is joined before the
+        // slot-attention / convolution kernels, which then have the machine to themselves (their timings stay comparable)
+        RC(fork_side(st));
+        std::swap(scratch_, scratch2_);
+        const int rc = bwd_dvae(side_);
+        std::swap(scratch_, scratch2_);
+        RC(rc);
+        RC(bwd_decoder(st));
+        RC(join_side(st));
+        RC(bwd_encoder(st));
     } else if (side_) {         // the dVAE backward only needs the forward's reconstruction gradient: it overlaps decoder + encoder
         RC(fork_side(st));
         std::swap(scratch_, scratch2_);

@@ -121,7 +121,7 @@ private:
     float *dd0_, *dd1_, *dd2_, *dd3_, *dd4_, *ps1_, *dd6_, *dd7_, *dd8_, *dd9_, *ps2_, *recon_, *drecon_;
     float *e1_, *e2_, *e3_, *e4_, *posmap_, *gridT_, *ln0_, *ln0_mean_, *ln0_rstd_, *h1_, *x_;
     float *slots0_, *slot_noise_, *slots_, *attn_, *sa_save_, *sa_wts_, *sa_grows_, *sa_small_, *sa_xchg_;
-    int* sa_counters_;
+    float* sa_parts_;
     PackEntry* sa_pack_dev_ = nullptr;
     int sa_pack_n_ = 0, sa_pack_max_ = 0;
     float *cw_fwd_[4], *cw_bwd_[4];       // CNN encoder conv packs

