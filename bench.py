@@ -191,7 +191,8 @@ def bench_iodine(args, dev, dist, rank, world):
     get_loss is excluded from the timed region, like SLATE's masks=None path)."""
     from ocrl_amd import ocrs
     from ocrl_amd.dist_utils import allreduce_grads_
-    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+    from ocrl_amd.utils.data import random_sprite_scenes
+    from ocrl_amd.utils.tools import obs_from_uint8
     S, B, K = args.obs_size, args.batch, args.num_slots
     ocr = NS(name="Iodine", slot_size=64, num_iterations=5, num_slots=K, img_channels=3, sigma=0.35, beta=1.0, layer_norm=True,
              ref_cnn_hidden_size=64, ref_mlp_hidden_size=256, ref_cnn_layers=4, ref_cnn_kernel_size=3, ref_cnn_stride_size=2,
@@ -202,11 +203,11 @@ def bench_iodine(args, dev, dist, rank, world):
     model.to(dev)
     model.train()
     model._module.set_seed(1 + rank)
-    pool = [scenes_to_obs(random_sprite_scenes(B, S, seed=1000 * rank + i)).to(dev) for i in range(4)]
+    pool = [torch.from_numpy(random_sprite_scenes(B, S, seed=1000 * rank + i)).to(dev) for i in range(4)]      # uint8 HWC, as a dataset stores them
     mod, lr = model._module, ocr.learning
 
     def step_fn(i):
-        out = mod._forward(pool[i % len(pool)])
+        out = mod._forward(obs_from_uint8(pool[i % len(pool)]))
         mod.backward()
         scale = allreduce_grads_(mod.engine.flat_g)
         model._opt.step(lr.clip, scale)
@@ -287,7 +288,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ocrl_amd import ocrs
-    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+    from ocrl_amd.utils.data import random_sprite_scenes
+    from ocrl_amd.utils.tools import obs_from_uint8
     S, B = args.obs_size, args.batch
     if args.workload == "iodine":
         return bench_iodine(args, dev, dist, rank, world)
@@ -300,10 +302,12 @@ def main():
     model.to(dev)
     model.train()
     model._module.set_seed(1 + rank)           # per-rank noise / dropout streams
-    pool = [scenes_to_obs(random_sprite_scenes(B, S, seed=1000 * rank + i)).to(dev) for i in range(4)]
+    # four batches of scenes resident in HBM as the dataset stores them (uint8 HWC); each step converts its batch on the device
+    # (utils/datasets.py:17 -> ocrl_obs_u8_to_f32), so the input pipeline's device side is inside the timed region
+    pool = [torch.from_numpy(random_sprite_scenes(B, S, seed=1000 * rank + i)).to(dev) for i in range(4)]
 
     def step_fn(i):
-        return model.update(pool[i % len(pool)], None, i)
+        return model.update(obs_from_uint8(pool[i % len(pool)]), None, i)
 
     # families timed live with HIP events: the 5x5 / 64-channel conv (roofline kernel) and the slot-attention loop (north-star kernel)
     dt, ms, cnt, metrics = timed_region(args, dev, dist, step_fn, (1 << 0) | (1 << 4) | (1 << 5))
@@ -327,7 +331,7 @@ def main():
         "config": {"workload": f"{name} {S}x{S}, {K} slots, 3 iters" + (", vocab 4096, d_model 192, 4 decoder blocks" if args.workload == "slate" else
                                ", CNN encoder + slot attention + spatial-broadcast decoder") +
                                "; full update() step (fwd+bwd+all-reduce+inf-norm clip+Adam), train mode dropout 0.1, device RNG; "
-                               "random-N5C4S4S2-style scenes",
+                               "random-N5C4S4S2-style uint8 scenes resident in HBM, converted on the device each step",
                    "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
         "roofline": mfma_roofline("conv_fwd_kernel<5,64,64> (5x5 conv 64->64, forward + backward-data launches" +
                                   (" of the CNN encoder on B images and of the broadcast decoder on B*K images)" if ocr.use_bcdec else " of the CNN encoder)"),

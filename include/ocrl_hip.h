@@ -121,6 +121,11 @@ int ocrl_attention_bwd(const float* q, const float* k, const float* v, const flo
  * tag bits: 0 conv5x5/64ch fwd+bwd-data, 1 other convs, 2 conv weight-grad, 3 gemm, 4 slot-attn fwd, 5 slot-attn bwd,
  * 6 self-attention fwd, 7 self-attention bwd.
  * ocrl_prof_collect synchronises the device and returns total milliseconds / launch counts per tag. */
+/* Input pipeline on the device: utils/datasets.py:13-24 (`torch.Tensor(obss[i]).permute(2, 0, 1) / 255.0`) + to_device
+ * (utils/tools.py:182-191, train_ocr.py:52-53).  The host uploads the dataset's uint8 HWC images as they are (a quarter of the
+ * fp32 bytes over PCIe); obs_chw = obs_hwc / 255 as correctly rounded fp32, bit-identical to the reference's conversion. */
+int ocrl_obs_u8_to_f32(const unsigned char* obs_hwc, float* obs_chw, int B, int H, int W, int C, void* stream);
+
 int ocrl_prof_enable(unsigned tag_mask);
 int ocrl_prof_collect(double* ms, long long* count, int ntags);
 

@@ -65,6 +65,7 @@ def lib():
     L.ocrl_layernorm_bwd.argtypes = [p, p, p, p, p, p, p, c_longlong, c_int, p, c_size_t, p]
     L.ocrl_attention_fwd.argtypes = [p, p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_uint, p]
     L.ocrl_attention_bwd.argtypes = [p, p, p, p, p, p, p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_uint, p]
+    L.ocrl_obs_u8_to_f32.argtypes = [p, p, c_int, c_int, c_int, c_int, p]
     L.ocrl_prof_enable.argtypes = [c_uint]
     L.ocrl_prof_collect.argtypes = [POINTER(ctypes.c_double * 8), POINTER(c_longlong * 8), c_int]
     L.ocrl_iodine_create.argtypes = [POINTER(IodineConfig), POINTER(p)]

@@ -32,6 +32,10 @@ struct ocrl_iodine {
 extern "C" {
 
 const char* ocrl_last_error(void) { return g_err; }
+int ocrl_obs_u8_to_f32(const unsigned char* obs_hwc, float* obs_chw, int B, int H, int W, int C, void* stream) {
+    if (!obs_hwc || !obs_chw || B < 1 || H < 1 || W < 1 || C < 1) { ocrl_set_error("ocrl_obs_u8_to_f32: bad arguments"); return 1; }
+    return obs_u8_to_f32_launch(obs_hwc, obs_chw, B, H, W, C, ST(stream));
+}
 int ocrl_abi_version(void) { return OCRL_ABI_VERSION; }
 
 int ocrl_slate_create(const ocrl_slate_config* c, ocrl_slate** out) {

@@ -1092,6 +1092,23 @@ int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, cons
     if (K <= 8) return cross_attn_bwd_launch_k<8>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, part, st);
     return cross_attn_bwd_launch_k<16>(dO, Q, Km, Vm, P, dQ, dKm, dVm, B, T, K, d, h, p, seed, site, part, st);
 }
+// Input pipeline on the device (reference: utils/datasets.py:13-24, `torch.Tensor(obss[i]).permute(2, 0, 1) / 255.0`):
+// uint8 [B,H,W,C] -> fp32 [B,C,H,W], a correctly rounded fp32 division by 255 (bit-identical to the reference's).  One thread per
+// pixel reads its C bytes and writes C planes; consecutive threads = consecutive pixels, so the plane writes are coalesced.
+__global__ void obs_u8_to_f32_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, long long npix_total, long long HW, int C) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix_total) return;
+    const long long b = i / HW, pix = i - b * HW;
+    const unsigned char* src = in + i * C;
+    float* dst = out + b * C * HW + pix;
+    for (int c = 0; c < C; ++c) dst[c * HW] = (float)src[c] / 255.0f;
+}
+int obs_u8_to_f32_launch(const unsigned char* in, float* out, int B, int H, int W, int C, hipStream_t st) {
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(obs_u8_to_f32_kernel, GRID1D(n), 0, st, in, out, n, (long long)H * W, C);
+    OCRL_CHECK_LAUNCH("obs_u8_to_f32");
+    return 0;
+}
 int fill_launch(float* x, long long n, float v, hipStream_t st) {
     hipLaunchKernelGGL(fill_kernel, GRID1D(n), 0, st, x, n, v);
     OCRL_CHECK_LAUNCH("fill");

@@ -98,6 +98,7 @@ size_t cross_attn_bwd_ws_floats(int B, int T, int K, int d, int h);
 int cross_attn_bwd_launch(const float* dO, const float* Q, const float* Km, const float* Vm, const float* P, float* dQ, float* dKm, float* dVm,
                           int B, int T, int K, int d, int h, float p, unsigned long long seed, unsigned site, float* part, size_t part_floats,
                           hipStream_t st);
+int obs_u8_to_f32_launch(const unsigned char* in, float* out, int B, int H, int W, int C, hipStream_t st);
 int fill_launch(float* x, long long n, float v, hipStream_t st);
 int axpy_launch(const float* x, float* y, long long n, float a, hipStream_t st);
 int posmap_launch(const float* Wpos, const float* bpos, float* out, int S, int C, hipStream_t st);

@@ -1,6 +1,8 @@
-"""Datasets for train_ocr.py.  Same sample format as the reference's utils/datasets.py:8-27 ("obss" float CHW in
-[0,1], optional "masks" [K+1,H,W,1] with the background last).  Reads the reference's HDF5 when h5py and the file
-are available, otherwise generates random-N5C4S4S2-style scenes deterministically per index."""
+"""Datasets for train_ocr.py.  Same sample content as the reference's utils/datasets.py:8-27 ("obss", optional "masks" [K+1,H,W,1] with
+the background last).  Reads the reference's HDF5 when h5py and the file are available, otherwise generates random-N5C4S4S2-style
+scenes deterministically per index.  With raw_uint8 (the default of get_dataloaders) a sample carries the image as the dataset stores
+it — "obss_u8", uint8 HWC — and the permute + /255 of utils/datasets.py:17 runs on the GPU (ocrl_obs_u8_to_f32) after a 4x smaller
+upload; raw_uint8=False gives the reference's float CHW "obss"."""
 import os
 
 import numpy as np
@@ -11,8 +13,14 @@ from .data import random_sprite_scenes
 
 
 class SyntheticScenes(Dataset):
-    def __init__(self, n, size, seed=0, with_masks=False, num_objs=5):
+    def __init__(self, n, size, seed=0, with_masks=False, num_objs=5, raw_uint8=False):
         self.n, self.size, self.seed, self.with_masks, self.num_objs = int(n), int(size), int(seed), bool(with_masks), num_objs
+        self.raw_uint8 = bool(raw_uint8)
+
+    def _obs(self, img):
+        if self.raw_uint8:
+            return {"obss_u8": torch.from_numpy(img)}
+        return {"obss": torch.from_numpy(img).permute(2, 0, 1).float() / 255.0}
 
     def __len__(self):
         return self.n
@@ -21,22 +29,25 @@ class SyntheticScenes(Dataset):
         s = (self.seed * 1000003 + index) & 0x7FFFFFFF
         if self.with_masks:
             img, m = random_sprite_scenes(1, self.size, seed=s, num_objs=self.num_objs, with_masks=True)
-            return {"obss": torch.from_numpy(img[0]).permute(2, 0, 1).float() / 255.0, "masks": torch.from_numpy(m[0])}
+            return {**self._obs(img[0]), "masks": torch.from_numpy(m[0])}
         img = random_sprite_scenes(1, self.size, seed=s, num_objs=self.num_objs)
-        return {"obss": torch.from_numpy(img[0]).permute(2, 0, 1).float() / 255.0}
+        return self._obs(img[0])
 
 
 class H5DataSet(Dataset):
     """utils/datasets.py:8-27"""
 
-    def __init__(self, data):
+    def __init__(self, data, raw_uint8=False):
         self._data = data
         self._num_samples = data["obss"].shape[0]
+        self._raw_uint8 = bool(raw_uint8)
 
     def __getitem__(self, index):
         res = {}
         for key in self._data.keys():
-            if key == "obss":
+            if key == "obss" and self._raw_uint8:
+                res["obss_u8"] = torch.from_numpy(np.ascontiguousarray(self._data[key][index], dtype=np.uint8))
+            elif key == "obss":
                 res[key] = torch.Tensor(self._data[key][index]).permute(2, 0, 1) / 255.0
             elif key == "labels":
                 res[key] = torch.LongTensor([self._data[key][index]])
@@ -48,7 +59,7 @@ class H5DataSet(Dataset):
         return self._num_samples
 
 
-def get_dataloaders(config, batch_size, num_workers, rank=0, world=1, seed=0):
+def get_dataloaders(config, batch_size, num_workers, rank=0, world=1, seed=0, raw_uint8=True):
     """utils/tools.py:155-178 without the wandb download path"""
     datafile = config.datadir if config.get("datadir") else None
     if datafile and os.path.isfile(datafile):
@@ -57,11 +68,11 @@ def get_dataloaders(config, batch_size, num_workers, rank=0, world=1, seed=0):
         except ImportError as e:
             raise RuntimeError(f"{datafile} exists but h5py is not installed") from e
         f = h5py.File(datafile, "r")
-        train, val = H5DataSet(f["TrainingSet"]), H5DataSet(f["ValidationSet"])
+        train, val = H5DataSet(f["TrainingSet"], raw_uint8), H5DataSet(f["ValidationSet"], raw_uint8)
     else:
         wm = bool(config.get("with_masks", False))
-        train = SyntheticScenes(config.get("synthetic_train", 100000), config.obs_size, seed=seed * 2 + 1, with_masks=wm)
-        val = SyntheticScenes(config.get("synthetic_val", 1000), config.obs_size, seed=seed * 2 + 2, with_masks=wm)
+        train = SyntheticScenes(config.get("synthetic_train", 100000), config.obs_size, seed=seed * 2 + 1, with_masks=wm, raw_uint8=raw_uint8)
+        val = SyntheticScenes(config.get("synthetic_val", 1000), config.obs_size, seed=seed * 2 + 2, with_masks=wm, raw_uint8=raw_uint8)
     sampler = None
     if world > 1:
         from torch.utils.data.distributed import DistributedSampler

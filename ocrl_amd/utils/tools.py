@@ -12,6 +12,20 @@ def to_device(batch, device):
     return batch.to(device)
 
 
+def obs_from_uint8(u8):
+    """uint8 [B,H,W,C] on the GPU -> fp32 [B,C,H,W] in [0,1] (utils/datasets.py:17 + the H2D copy of train_ocr.py:52-53), converted by
+    the library's kernel: the host ships a quarter of the bytes and never touches the pixels"""
+    import ctypes
+    from .. import _lib
+    if not (u8.is_cuda and u8.dtype == torch.uint8 and u8.dim() == 4):
+        raise RuntimeError("obs_from_uint8: expected a uint8 [B,H,W,C] tensor on the GPU")
+    u8 = u8.contiguous()
+    B, H, W, C = u8.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=u8.device)
+    _lib.check(_lib.lib().ocrl_obs_u8_to_f32(_lib.ptr(u8), _lib.ptr(out), B, H, W, C, ctypes.c_void_p(torch.cuda.current_stream(u8.device).cuda_stream)))
+    return out
+
+
 def get_item(x):
     """utils/tools.py:195-199"""
     if not torch.is_tensor(x):

@@ -56,11 +56,17 @@ def test_dataset_and_loader_sample_format():
     from ocrl_amd.utils.datasets import get_dataloaders
     c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2", "dataset.synthetic_train=16", "dataset.synthetic_val=8",
                                    "dataset.with_masks=True"])
-    tr, va = get_dataloaders(c.dataset, 4, 0)
+    tr, va = get_dataloaders(c.dataset, 4, 0, raw_uint8=False)          # the reference's sample format (utils/datasets.py:13-24)
     b = next(iter(tr))
     assert b["obss"].shape == (4, 3, 64, 64) and b["obss"].dtype == torch.float32 and 0 <= b["obss"].min() and b["obss"].max() <= 1
     assert b["masks"].permute(0, 1, 4, 2, 3).shape == (4, 6, 1, 64, 64)
     assert len(va.dataset) == 8
+    # default: the stored uint8 HWC image travels, the conversion runs on the GPU; both describe the same pixels
+    tr8, _ = get_dataloaders(c.dataset, 4, 0)
+    b8 = next(iter(tr8))
+    assert b8["obss_u8"].shape == (4, 64, 64, 3) and b8["obss_u8"].dtype == torch.uint8 and "obss" not in b8
+    s0, s8 = tr.dataset[3], tr8.dataset[3]
+    assert torch.equal(s8["obss_u8"].permute(2, 0, 1).float() / 255.0, s0["obss"]) and torch.equal(s0["masks"], s8["masks"])
 
 
 def test_ari_matches_sklearn():

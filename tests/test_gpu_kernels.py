@@ -171,3 +171,13 @@ def test_layernorm(L, R, Fd):
     e = [relerr(yo.cpu(), y), relerr(dx.cpu(), x.grad), relerr(dgb[:Fd].cpu(), gam.grad), relerr(dgb[Fd:].cpu(), bet.grad)]
     log(f"layernorm R{R} F{Fd}: y {e[0]:.2e} dx {e[1]:.2e} dgamma {e[2]:.2e} dbeta {e[3]:.2e}")
     assert max(e) < TOL
+
+
+@pytest.mark.parametrize("B,S,C", [(3, 64, 3), (2, 37, 3), (1, 16, 1)])
+def test_obs_uint8_to_float_is_bit_identical_to_the_reference_conversion(L, B, S, C):
+    """utils/datasets.py:17: torch.Tensor(obss[i]).permute(2, 0, 1) / 255.0 — here on the GPU from the uploaded uint8 HWC batch"""
+    from ocrl_amd.utils.tools import obs_from_uint8
+    u8 = torch.randint(0, 256, (B, S, S, C), dtype=torch.uint8, generator=torch.Generator().manual_seed(S))
+    ref = torch.stack([torch.Tensor(u8[i].numpy()).permute(2, 0, 1) / 255.0 for i in range(B)])
+    got = obs_from_uint8(u8.cuda())
+    assert got.shape == (B, C, S, S) and torch.equal(got.cpu(), ref)

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 from ocrl_amd import ocrs  # noqa: E402
 from ocrl_amd.utils.config import compose  # noqa: E402
 from ocrl_amd.utils.datasets import get_dataloaders  # noqa: E402
-from ocrl_amd.utils.tools import get_item, to_device  # noqa: E402
+from ocrl_amd.utils.tools import get_item, obs_from_uint8, to_device  # noqa: E402
 
 log = logging.getLogger("train_ocr")
 
@@ -56,7 +56,8 @@ def save(model, run_dir, step=0, epoch=0, best_val_loss=1e5, best=False):
 
 
 def batch_inputs(batch, device):
-    obs = to_device(batch["obss"], device)
+    """train_ocr.py:52-53 + utils/datasets.py:17: the uint8 images are uploaded as stored and converted (HWC -> CHW, /255) on the GPU"""
+    obs = obs_from_uint8(to_device(batch["obss_u8"], device)) if "obss_u8" in batch else to_device(batch["obss"], device)
     masks = to_device(batch["masks"].permute(0, 1, 4, 2, 3), device) if "masks" in batch else None
     return obs, masks
 
