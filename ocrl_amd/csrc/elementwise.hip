@@ -852,12 +852,13 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
     if (i < n) dst[i] = src[i];
 }
 
-// tokens[b*T + t] = argmax_v pred[(b*T + t)*V + v] for one position t of every image (first index wins ties)
-__global__ __launch_bounds__(256) void argmax_pos_kernel(const float* __restrict__ pred, int* __restrict__ tokens, int T, int V, int t) {
+// tokens[b*T + t] = argmax_v of image b's logits at position t (first index wins ties); the logits are row b*T + t of a [B*T, V]
+// matrix, or row b of a [B, V] matrix holding only position t (dense_rows: the KV-cached decode)
+__global__ __launch_bounds__(256) void argmax_pos_kernel(const float* __restrict__ pred, int* __restrict__ tokens, int T, int V, int t, int dense_rows) {
     __shared__ float rv[4];
     __shared__ int ri[4];
     const long long row = (long long)blockIdx.x * T + t;
-    const float* r = pred + row * V;
+    const float* r = pred + (dense_rows ? (long long)blockIdx.x : row) * V;
     float best = -INFINITY;
     int bi = 0;
     for (int v = threadIdx.x; v < V; v += 256) { const float x = r[v]; if (x > best) { best = x; bi = v; } }
@@ -874,6 +875,66 @@ __global__ __launch_bounds__(256) void argmax_pos_kernel(const float* __restrict
         tokens[row] = bi;
     }
 }
+// ---- KV-cached greedy decode (SLATE_Module._gen_imgs, ocrs/slate/slate_module.py:163-179): one new token per image and step
+// x[b] = (t == 0 ? BOS : dictionary[tokens[b][t-1]]) + pe[t]          (slate_module.py:167-176, transformer.py:66; no dropout in eval)
+__global__ void embed_step_kernel(const int* __restrict__ tokens, const float* __restrict__ dict, const float* __restrict__ bos,
+                                  const float* __restrict__ pe, float* __restrict__ out, int B, int T, int d, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, c = i - b * d;
+    const float* src = t == 0 ? bos : dict + (size_t)tokens[b * T + t - 1] * d;
+    out[i] = src[c] + pe[(size_t)t * d + c];
+}
+// Causal self-attention of the newest token against the cached keys / values (transformer.py:31-47 restricted to query row t):
+// qkv is the fused projection buffer [B*T, ld] (q | k | v side by side), rows b*T + 0..t of image b are filled; out [B, d].
+// One workgroup per (image, head): scores in LDS, softmax, then channels x key-slices accumulate P.V.
+__global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int T, int t, int d, int h, int ld) {
+    extern __shared__ float sm[];
+    const int dh = d / h, nk = t + 1, tid = threadIdx.x;
+    float* sc = sm;                  // [nk] scores -> probabilities
+    float* qs = sc + ((T + 3) & ~3); // [dh]
+    float* red = qs + 64;            // [256]
+    const int b = blockIdx.x / h, hd = blockIdx.x % h;
+    const float* base = qkv + (size_t)b * T * ld + hd * dh;
+    const float scale = rsqrtf((float)dh);
+    if (tid < dh) qs[tid] = base[(size_t)t * ld + tid] * scale;
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = tid; j < nk; j += 256) {
+        const float* kr = base + (size_t)j * ld + d;
+        float a = 0.f;
+        for (int c = 0; c < dh; c += 4) {
+            const float4 kv = *reinterpret_cast<const float4*>(kr + c);
+            a += qs[c] * kv.x + qs[c + 1] * kv.y + qs[c + 2] * kv.z + qs[c + 3] * kv.w;
+        }
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < nk; j += 256) { const float e = __expf(sc[j] - mx); sc[j] = e; sum += e; }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = 1.0f / red[0];
+    __syncthreads();
+    const int nsl = 256 / dh, c = tid % dh, sl = tid / dh;
+    float acc = 0.f;
+    if (sl < nsl)
+        for (int j = sl; j < nk; j += nsl) acc += sc[j] * base[(size_t)j * ld + 2 * d + c];
+    red[tid] = sl < nsl ? acc : 0.f;
+    __syncthreads();
+    if (tid < dh) {
+        float a = 0.f;
+        for (int k = 0; k < nsl; ++k) a += red[k * dh + tid];
+        out[(size_t)b * d + hd * dh + tid] = a * inv;
+    }
+}
+
 // z[row][v] = (v == tokens[row])
 __global__ void onehot_kernel(const int* __restrict__ tokens, float* __restrict__ z, long long n, int V) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1150,9 +1211,22 @@ int copy_launch(const float* src, float* dst, long long n, hipStream_t st) {
     OCRL_CHECK_LAUNCH("copy");
     return 0;
 }
-int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_pos_kernel, dim3(B), dim3(256), 0, st, pred, tokens, T, V, t);
+int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t, hipStream_t st, int dense_rows) {
+    hipLaunchKernelGGL(argmax_pos_kernel, dim3(B), dim3(256), 0, st, pred, tokens, T, V, t, dense_rows);
     OCRL_CHECK_LAUNCH("argmax_pos");
+    return 0;
+}
+int embed_step_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, int t, hipStream_t st) {
+    hipLaunchKernelGGL(embed_step_kernel, GRID1D((long long)B * d), 0, st, tokens, dict, bos, pe, out, B, T, d, t);
+    OCRL_CHECK_LAUNCH("embed_step");
+    return 0;
+}
+int decode_attn_launch(const float* qkv, float* out, int B, int T, int t, int d, int h, int ld, hipStream_t st) {
+    OCRL_REQUIRE(d % h == 0 && (d / h) % 4 == 0 && (d / h) <= 64 && t >= 0 && t < T && ld % 4 == 0, "decode_attn: unsupported shape");
+    const size_t smem = (size_t)(((T + 3) & ~3) + 64 + 256) * 4;
+    OCRL_REQUIRE(smem <= 64 * 1024, "decode_attn: sequence too long for the LDS score buffer (T = %d)", T);
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(B * h), dim3(256), smem, st, qkv, out, T, t, d, h, ld);
+    OCRL_CHECK_LAUNCH("decode_attn");
     return 0;
 }
 int onehot_launch(const int* tokens, float* z, long long rows, int V, hipStream_t st) {

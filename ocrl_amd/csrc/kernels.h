@@ -177,7 +177,9 @@ int clip_adam_launch(float* p, const float* g, float* m, float* v, long long n, 
 int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st);
 int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float* noise, float* dmu, float* dlogsig, int BK, int D, unsigned long long seed, hipStream_t st);
 int copy_launch(const float* src, float* dst, long long n, hipStream_t st);
-int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t, hipStream_t st);
+int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t, hipStream_t st, int dense_rows = 0);
+int embed_step_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, int t, hipStream_t st);
+int decode_attn_launch(const float* qkv, float* out, int B, int T, int t, int d, int h, int ld, hipStream_t st);
 int onehot_launch(const int* tokens, float* z, long long rows, int V, hipStream_t st);
 
 // ------------------------------------------------------------------ attention.hip

@@ -540,20 +540,51 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
     return 0;
 }
 
-// SLATE_Module._gen_imgs (slate_module.py:163-179): greedy autoregressive token decode from the projected slots,
-// then the dVAE decoder.  The reference re-runs the decoder on the growing prefix; the causal mask makes a full-length
-// pass with the not-yet-generated tokens as placeholders give the same logits at position t, so each of the T steps is
-// one full decoder forward here.  Clobbers the decoder activations: no backward() afterwards.  metrics[4] = mse.
+// SLATE_Module._gen_imgs (slate_module.py:163-179): greedy autoregressive token decode from the projected slots, then the dVAE
+// decoder.  The reference re-runs the whole decoder on the growing prefix for every token (O(T^2) decoder rows); the causal mask makes
+// the rows of earlier positions independent of later tokens, so here every step pushes ONE new row per image through the blocks and
+// attends to the keys / values of the earlier rows kept in the fused q|k|v buffer of each block (KV cache): T steps of B rows instead
+// of T passes of up to B*T rows.  Clobbers the decoder activations: no backward() afterwards.  metrics[4] = mse of the generated image.
 int SlateModel::generate(hipStream_t st) {
     OCRL_REQUIRE(!cfg.use_bcdec, "generate: the autoregressive decoder is not part of the use_bcdec configuration");
     OCRL_REQUIRE(last_.B > 0 && last_.obs, "generate: run forward or encode first");
     const int B = last_.B;
+    const long long BK = (long long)B * K;
     pdrop_ = 0.f;
     have_fwd_ = false;
     OCRL_HIP(hipMemsetAsync(tokens_, 0, sizeof(int) * (size_t)B * T, st));
+    // slot side, once: projected slots and every block's cross-attention keys / values
+    RC(lin_fwd(slots_, D, P("_slotproj.weight"), nullptr, mem_, d, BK, d, D, 0, nullptr, 0, 0.f, 0, st));
+    for (int b = 0; b < NB; ++b) {
+        const std::string pre = fmt("_tfdec.blocks.%d.", b);
+        RC(lin_fwd(mem_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, blk_[b].ck, d, BK, d, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(lin_fwd(mem_, d, P(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, blk_[b].cv, d, BK, d, d, 0, nullptr, 0, 0.f, 0, st));
+    }
+    float* x0 = emb_;           // [B, d] rows of the current step (the first rows of the full-size training buffers)
     for (int t = 0; t < T; ++t) {
-        RC(fwd_decoder(st, false));
-        RC(argmax_pos_launch(pred_, tokens_, B, T, V, t, st));
+        RC(embed_step_launch(tokens_, P("_dict.dictionary.weight"), P("_bos_token._bos_token"), P("_z_pos.pe"), x0, B, T, d, t, st));
+        const float* xin = x0;
+        for (int b = 0; b < NB; ++b) {
+            Blk& k = blk_[b];
+            const std::string pre = fmt("_tfdec.blocks.%d.", b);
+            RC(layernorm_fwd_launch(xin, P(pre + "self_attn_layer_norm.weight"), P(pre + "self_attn_layer_norm.bias"), k.ln1, k.ln1_mean, k.ln1_rstd, B, d, st));
+            const float* res = (b == 0) ? k.ln1 : xin;
+            // q | k | v of the new row go straight into row t of each image's cache: output row m lives at (m*T + t) * 3d
+            RC(lin_fwd(k.ln1, d, P(pre + "self_attn.proj_q.weight"), nullptr, k.q + (size_t)t * 3 * d, T * 3 * d, B, 3 * d, d, 0, nullptr, 0, 0.f, 0, st));
+            RC(decode_attn_launch(k.q, k.ao, B, T, t, d, NH, 3 * d, st));
+            RC(lin_fwd(k.ao, d, P(pre + "self_attn.proj_o.weight"), nullptr, k.x1, d, B, d, d, 0, res, d, 0.f, 0, st));
+            RC(layernorm_fwd_launch(k.x1, P(pre + "encoder_decoder_attn_layer_norm.weight"), P(pre + "encoder_decoder_attn_layer_norm.bias"), k.ln2, k.ln2_mean, k.ln2_rstd, B, d, st));
+            RC(lin_fwd(k.ln2, d, P(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, k.cq, d, B, d, d, 0, nullptr, 0, 0.f, 0, st));
+            RC(cross_attn_fwd_launch(k.cq, k.ck, k.cv, k.cao, k.cP, B, 1, K, d, NH, 0.f, 0, 0, st));
+            RC(lin_fwd(k.cao, d, P(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, k.x2, d, B, d, d, 0, k.x1, d, 0.f, 0, st));
+            RC(layernorm_fwd_launch(k.x2, P(pre + "ffn_layer_norm.weight"), P(pre + "ffn_layer_norm.bias"), k.ln3, k.ln3_mean, k.ln3_rstd, B, d, st));
+            RC(lin_fwd(k.ln3, d, P(pre + "ffn.0.weight"), P(pre + "ffn.0.bias"), k.f1, 4 * d, B, 4 * d, d, 1, nullptr, 0, 0.f, 0, st));
+            RC(lin_fwd(k.f1, 4 * d, P(pre + "ffn.2.weight"), P(pre + "ffn.2.bias"), k.x3, d, B, d, 4 * d, 0, k.x2, d, 0.f, 0, st));
+            xin = k.x3;
+        }
+        RC(layernorm_fwd_launch(xin, P("_tfdec.layer_norm.weight"), P("_tfdec.layer_norm.bias"), lnf_, lnf_mean_, lnf_rstd_, B, d, st));
+        RC(lin_fwd(lnf_, d, P("_out.weight"), nullptr, pred_, V, B, V, d, 0, nullptr, 0, 0.f, 0, st));
+        RC(argmax_pos_launch(pred_, tokens_, B, T, V, t, st, 1));
     }
     RC(onehot_launch(tokens_, z_, (long long)B * T, V, st));
     RC(dvae_decode(B, nullptr, st, z_));

@@ -273,20 +273,22 @@ def test_broadcast_decoder_config_matches_oracle(tag, over, B):
         assert wp < 1e-5
 
 
-def test_autoregressive_generation_matches_oracle():
-    """_gen_imgs (slate_module.py:163-179): greedy token decode + dVAE decode against a plain restatement on the oracle"""
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("a64", dict(obs_size=64, num_slots=6, num_iterations=3), 2)])
+def test_autoregressive_generation_matches_oracle(tag, over, B):
+    """_gen_imgs (slate_module.py:163-179): the KV-cached greedy decode + dVAE decode against the reference's growing-prefix loop restated
+    on the oracle (a64: real 64x64 configuration, T = 256 tokens, vocab 4096, 4 blocks)"""
     import torch.nn.functional as F
-    cfg = O.default_cfg(**SMALL)
-    B = 2
+    cfg = O.default_cfg(**over)
     P = O.formula_params(cfg)
     eng = make_engine(cfg, B)
     load_params(eng, P)
-    obs = torch.rand(B, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    S, E = cfg.obs_size, cfg.obs_size // 4
+    obs = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(3))
     noise = O.make_noise(cfg, B, 4)
     eng.forward(obs.cuda(), 1.0, train=False, seed=0, noise=dev_noise(cfg, noise))
     eng.generate()
     torch.cuda.synchronize()
-    T, V, E = 16, cfg.vocab_size, 4
+    T, V = E * E, cfg.vocab_size
     # oracle: grow the prefix exactly as the reference does
     feats = O.cnn_encode(P, obs)
     slots, _ = O.slot_encoder(P, feats, noise["slots"], cfg)
@@ -303,10 +305,10 @@ def test_autoregressive_generation_matches_oracle():
     rec = O.dvae_decode(P, zg)
     got_tok = eng.tensor("tokens", (B, T), torch.int32).cpu().long()
     assert torch.equal(got_tok, toks), (got_tok, toks)
-    e = relerr(eng.tensor("recon", (B, 16, 16, 4))[..., :3].permute(0, 3, 1, 2), rec)
+    e = relerr(eng.tensor("recon", (B, S, S, 4))[..., :3].permute(0, 3, 1, 2), rec)
     mse = ((obs - rec) ** 2).sum() / B
     em = abs(eng.metrics.cpu()[4].item() - mse.item()) / mse.item()
-    log(f"[gen_imgs] recon {e:.2e} mse {em:.2e}")
+    log(f"[gen_imgs {tag}] {T} tokens exact, recon {e:.2e} mse {em:.2e}")
     assert e < 1e-4 and em < 1e-5
 
 
