@@ -181,3 +181,25 @@ def test_obs_uint8_to_float_is_bit_identical_to_the_reference_conversion(L, B, S
     ref = torch.stack([torch.Tensor(u8[i].numpy()).permute(2, 0, 1) / 255.0 for i in range(B)])
     got = obs_from_uint8(u8.cuda())
     assert got.shape == (B, C, S, S) and torch.equal(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N", [(16384, 192), (16416, 576), (32768, 768)])
+def test_gemm_model_width_many_rows(L, M, N):
+    """K = 192, N a multiple of 192, >= 16k rows (the decoder's products at benchmark scale, several waves of workgroups): NT with
+    bias + ReLU and alpha + residual, NN (dX form) with an activation mask"""
+    K = 192
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    out = run_gemm(L, dev(A), dev(W), M, N, K, 1, 1, bias=dev(b), relu=1)
+    e1 = relerr(out, torch.relu(A.double() @ W.double().T + b.double()))
+    out2 = run_gemm(L, dev(A), dev(W), M, N, K, 1, 1, alpha=0.5, resid=dev(R))
+    e2 = relerr(out2, 0.5 * (A.double() @ W.double().T) + R.double())
+    Wn = torch.randn(K, N, generator=g) / K ** 0.5          # dX = dY W, W stored [N_out = K, K_in = N]
+    act = torch.randn(M, N, generator=g)
+    out3 = run_gemm(L, dev(A), dev(Wn), M, N, K, 1, 0, mask=dev(act))
+    e3 = relerr(out3, (A.double() @ Wn.double()) * (act > 0))
+    log(f"gemm model-width {M}x{N}x192: NT bias+relu {e1:.2e} alpha+resid {e2:.2e} NN mask {e3:.2e}")
+    assert max(e1, e2, e3) < TOL

@@ -14,6 +14,7 @@ P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 SHAPES = [  # (name, M, N, K, akc, bkc, splitk)
     ("proj NT 131072x192x192", 131072, 192, 192, 1, 1, 1),
     ("proj NN 131072x192x192", 131072, 192, 192, 1, 0, 1),
+    ("qkv NT 131072x576x192", 131072, 576, 192, 1, 1, 1),
     ("ffn1 NT 131072x768x192", 131072, 768, 192, 1, 1, 1),
     ("ffn2 NT 131072x192x768", 131072, 192, 768, 1, 1, 1),
     ("ffn2dx NN 131072x768x192", 131072, 768, 192, 1, 0, 1),
