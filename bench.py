@@ -270,6 +270,9 @@ def main():
     ap.add_argument("--workload", choices=["slate", "slotattn", "iodine"], default="slate",
                     help="slotattn = BASELINE config 2 (use_bcdec); iodine = config 4 (use --obs-size 64 --num-slots 7); headline = slate")
     ap.add_argument("--dropout", type=float, default=0.1, help="diagnostic only: the headline number uses the reference default 0.1")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: all ranks share cuda:0 and reduce over gloo, to rehearse the N > 1 launch / barrier / reduction "
+                         "plumbing on a one-GPU box (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -279,13 +282,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ocrl_amd import ocrs
     from ocrl_amd.utils.data import random_sprite_scenes
@@ -359,6 +367,8 @@ def main():
                                          "around its launches; MFMA-busy / HBM PMC counters: profiles/r02_pmc_*"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec))
+    if args.rehearse_on_one_gpu:
+        out["rehearsal"] = "all ranks on cuda:0, gradients reduced over gloo: exercises the launch / barrier / reduction plumbing only, not a measurement"
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
