@@ -24,7 +24,7 @@ __device__ inline bool io_valid(int c, int k) { return !(c == 0 && k == 0) && !(
 // slots = mu + exp(ls) * eps (eps injected or drawn: Box-Muller on the counter RNG, stored for the backward);
 // kl_out += sum(-ls + (exp(2 ls) + mu^2)/2 - 1/2)
 __global__ __launch_bounds__(256) void io_sample_kernel(const float* __restrict__ mu, const float* __restrict__ ls, const float* __restrict__ noise,
-                                                        float* __restrict__ eps_out, float* __restrict__ slots, float* __restrict__ kl_out, long long n,
+                                                        float* __restrict__ eps_out, float* __restrict__ slots, float* __restrict__ kl_elem, long long n,
                                                         unsigned long long seed, unsigned site) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     float kl = 0.f;
@@ -40,8 +40,17 @@ __global__ __launch_bounds__(256) void io_sample_kernel(const float* __restrict_
         slots[i] = m + s * e;
         kl = -l + 0.5f * (s * s + m * m) - 0.5f;
     }
-    kl = wave_sum(kl);
-    if ((threadIdx.x & 63) == 0) atomicAdd(kl_out, kl);
+    if (i < n) kl_elem[i] = kl;
+}
+// out[0] = sum of x[0..n) in a fixed order (one workgroup: strided partial sums, then a tree): bitwise reproducible
+__global__ __launch_bounds__(1024) void io_ordered_sum_kernel(const float* __restrict__ x, long long n, long long stride, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float a = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) a += x[i * stride];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------- decoder layer 1
@@ -98,8 +107,9 @@ __global__ void io_layer1_kernel(const float* __restrict__ P1, const float* __re
     const float4 t = *reinterpret_cast<const float4*>(T + (bk * 9 + io_cls(y, S) * 3 + io_cls(x, S)) * 64 + c4 * 4);
     *reinterpret_cast<float4*>(c1 + i * 4) = make_float4(elu_(p.x + t.x), elu_(p.y + t.y), elu_(p.z + t.z), elu_(p.w + t.w));
 }
-// dT[bk][cls][co] += sum over the pixels of row y in each column class of g[bk][y][x][co]   (one block per (bk, y); dT zeroed by the caller)
-__global__ __launch_bounds__(256) void io_layer1_bwd_kernel(const float* __restrict__ g, float* __restrict__ dT, int S) {
+// rowpart[bk][y][c][co] = sum over the pixels of row y in column class c of g[bk][y][x][co]   (one block per (bk, y));
+// io_layer1_reduce_kernel sums the rows of each row class in row order (no float atomics: bitwise reproducible)
+__global__ __launch_bounds__(256) void io_layer1_bwd_kernel(const float* __restrict__ g, float* __restrict__ rowpart, int S) {
     __shared__ float red[4][3][64];
     const long long bk = blockIdx.x / S;
     const int y = blockIdx.x % S;
@@ -110,10 +120,20 @@ __global__ __launch_bounds__(256) void io_layer1_bwd_kernel(const float* __restr
     for (int c = 0; c < 3; ++c) red[part][c][co] = a[c];
     __syncthreads();
     if (part == 0) {
-        const int rc = io_cls(y, S);
-        for (int c = 0; c < 3; ++c)
-            atomicAdd(&dT[(bk * 9 + rc * 3 + c) * 64 + co], red[0][c][co] + red[1][c][co] + red[2][c][co] + red[3][c][co]);
+        for (int c = 0; c < 3; ++c) rowpart[((bk * S + y) * 3 + c) * 64 + co] = (red[0][c][co] + red[1][c][co]) + (red[2][c][co] + red[3][c][co]);
     }
+}
+// dT[bk][rc*3+c][co] = sum over the rows y of row class rc of rowpart[bk][y][c][co]
+__global__ void io_layer1_reduce_kernel(const float* __restrict__ rowpart, float* __restrict__ dT, long long n, int S) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [BK][9][64]
+    if (i >= n) return;
+    const int co = i & 63, cls = (i >> 6) % 9;
+    const long long bk = i / (9 * 64);
+    const int rc = cls / 3, c = cls - rc * 3;
+    const int y0 = rc == 0 ? 0 : (rc == 1 ? 1 : S - 1), y1 = rc == 1 ? S - 1 : y0 + 1;
+    float a = 0.f;
+    for (int y = y0; y < y1; ++y) a += rowpart[((bk * S + y) * 3 + c) * 64 + co];
+    dT[i] = a;
 }
 // Weight gradient of layer 1 from the accumulated pieces: dW1[co][ci<L][tap] = dW1r[tap][co][ci];
 // dW1[co][L+j][tap] = sum_{pixels where tap is inside} G[y][x][co] * coord_j;  db1[co] = sum G   (one block per tap)
@@ -155,9 +175,12 @@ __global__ __launch_bounds__(256) void io_w1_grad_kernel(const float* __restrict
 //   dout4 [B*K][N][4] = d(B*elbo)/d(out4) (the in-forward gradient that is pushed through the decoder)
 template <int MAXK>
 __global__ __launch_bounds__(256) void io_elbo_kernel(const float* __restrict__ out4, const float* __restrict__ obs, int B, int K, int S, float sigma,
-                                                      float* __restrict__ enc, float* __restrict__ st1, float* __restrict__ dout4,
-                                                      float* __restrict__ part, float* __restrict__ masks_out, float* __restrict__ recon_out,
+                                                      float* __restrict__ enc, float* __restrict__ blkpart, float* __restrict__ dout4,
+                                                      float* __restrict__ masks_out, float* __restrict__ recon_out,
                                                       float* __restrict__ rmasked_out) {
+    __shared__ float red[4][4 * MAXK + 2];
+    for (int i = threadIdx.x; i < 4 * (4 * MAXK + 2); i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
     const int N = S * S;
     const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = gi / N, pix = gi % N;          // N % 256 == 0: a block never straddles two images
@@ -253,18 +276,41 @@ __global__ __launch_bounds__(256) void io_elbo_kernel(const float* __restrict__ 
                 e[0] = x[0]; e[1] = x[1]; e[2] = x[2]; e[3] = r[k][0]; e[4] = r[k][1]; e[5] = r[k][2]; e[6] = m[k]; e[7] = a[k]; e[8] = A[k] - lsA;
                 e[9] = g0; e[10] = g1; e[11] = g2; e[12] = mg[k]; e[13] = like; e[14] = loo; e[15] = cx; e[16] = cy;
                 const float s0 = wave_sum(g0 + g1 + g2), s1 = wave_sum(mg[k]), s2 = wave_sum(like), s3 = wave_sum(loo);
-                if (lane == 0) {
-                    float* st = st1 + ((size_t)b * K + k) * 4;
-                    atomicAdd(st + 0, s0); atomicAdd(st + 1, s1); atomicAdd(st + 2, s2); atomicAdd(st + 3, s3);
-                }
+                if (lane == 0) { float* r4 = &red[threadIdx.x >> 6][4 * k]; r4[0] = s0; r4[1] = s1; r4[2] = s2; r4[3] = s3; }
             }
     }
     ll = wave_sum(ll);
     mse = wave_sum(mse);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(part + 0, ll); atomicAdd(part + 1, mse); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][4 * MAXK] = ll; red[threadIdx.x >> 6][4 * MAXK + 1] = mse; }
+    __syncthreads();
+    // this block's partial [4 MAXK + 2]: the four waves in order (io_elbo_reduce_kernel sums the blocks in order)
+    if ((int)threadIdx.x < 4 * MAXK + 2) blkpart[(size_t)blockIdx.x * (4 * MAXK + 2) + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-// second pass of the 5-D layer norm: st2[bk][g] += sum (v - mean)^2, mean = st1 / count   (one thread per (bk, pixel))
-__global__ __launch_bounds__(256) void io_enc_var_kernel(const float* __restrict__ enc, const float* __restrict__ st1, float* __restrict__ st2, int N) {
+// st1[b*K + k][g] = sum over the N/256 blocks of image b (in order) of blkpart[blk][4k + g];  part[0..1] += sum over all blocks of (ll, mse)
+template <int MAXK>
+__global__ __launch_bounds__(256) void io_elbo_reduce_kernel(const float* __restrict__ blkpart, float* __restrict__ st1, float* __restrict__ part, int B, int K,
+                                                            int nb_img, int with_st1) {
+    constexpr int W = 4 * MAXK + 2;
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x;
+    if (with_st1)
+        for (int i = tid; i < B * K * 4; i += 256) {
+            const int g = i & 3, k = (i >> 2) % K, b = i / (4 * K);
+            float a = 0.f;
+            for (int j = 0; j < nb_img; ++j) a += blkpart[((size_t)b * nb_img + j) * W + 4 * k + g];
+            st1[i] = a;
+        }
+    float l = 0.f, m = 0.f;
+    for (int j = tid; j < B * nb_img; j += 256) { l += blkpart[(size_t)j * W + 4 * MAXK]; m += blkpart[(size_t)j * W + 4 * MAXK + 1]; }
+    red[0][tid] = l; red[1][tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; } __syncthreads(); }
+    if (tid == 0) { part[0] += red[0][0]; part[1] += red[1][0]; }
+}
+// second pass of the 5-D layer norm: blkpart[block][g] = sum over the block's pixels of (v - mean)^2, mean = st1 / count   (one thread
+// per (bk, pixel); io_enc_var_reduce_kernel sums the N/256 blocks of a (bk) in order)
+__global__ __launch_bounds__(256) void io_enc_var_kernel(const float* __restrict__ enc, const float* __restrict__ st1, float* __restrict__ blkpart, int N) {
+    __shared__ float red[4][4];
     const long long gi = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long bk = gi / N;
     const float* e = enc + gi * IO_ENC;
@@ -272,10 +318,18 @@ __global__ __launch_bounds__(256) void io_enc_var_kernel(const float* __restrict
     const float m0 = s[0] / (3.f * N), m1 = s[1] / N, m2 = s[2] / N, m3 = s[3] / N;
     const float d0 = e[9] - m0, d1 = e[10] - m0, d2 = e[11] - m0, d3 = e[12] - m1, d4 = e[13] - m2, d5 = e[14] - m3;
     const float v0 = wave_sum(d0 * d0 + d1 * d1 + d2 * d2), v1 = wave_sum(d3 * d3), v2 = wave_sum(d4 * d4), v3 = wave_sum(d5 * d5);
-    if ((threadIdx.x & 63) == 0) {
-        float* t = st2 + bk * 4;
-        atomicAdd(t + 0, v0); atomicAdd(t + 1, v1); atomicAdd(t + 2, v2); atomicAdd(t + 3, v3);
-    }
+    if ((threadIdx.x & 63) == 0) { float* t = red[threadIdx.x >> 6]; t[0] = v0; t[1] = v1; t[2] = v2; t[3] = v3; }
+    __syncthreads();
+    if (threadIdx.x < 4) blkpart[(size_t)blockIdx.x * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void io_enc_var_reduce_kernel(const float* __restrict__ blkpart, float* __restrict__ st2, long long n, int nb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over [BK][4]
+    if (i >= n) return;
+    const long long bk = i >> 2;
+    const int g = i & 3;
+    float a = 0.f;
+    for (int j = 0; j < nb; ++j) a += blkpart[((size_t)bk * nb + j) * 4 + g];
+    st2[i] = a;
 }
 // (v - mean) / (sqrt(var) + 1e-5), population variance over (C,H,W)  (iodine_module.py:316-329); layer_norm == 0 leaves the raw values
 __global__ __launch_bounds__(256) void io_enc_norm_kernel(float* __restrict__ enc, const float* __restrict__ st1, const float* __restrict__ st2, int N) {
@@ -558,12 +612,15 @@ __global__ void io_post_grad_kernel(const float* __restrict__ mu, const float* _
 }
 // sqrt in place (L2 norm from the sum of squares)
 __global__ void io_sqrt_kernel(float* x) { x[0] = sqrtf(x[0]); }
-// sum of squares: out[0] += sum g^2 (out zeroed by the caller)
-__global__ __launch_bounds__(256) void io_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+// sum of squares: blkpart[block] = this block's share (io_ordered_sum_kernel adds the blocks in a fixed order)
+__global__ __launch_bounds__(256) void io_sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ blkpart) {
+    __shared__ float red[4];
     float a = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) a += g[i] * g[i];
     a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) blkpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // loss = -sum_i w_i (ll_i / B - beta kl_i / B); metrics: [0] loss, [1] mse (last iteration), [2] kld (last iteration)
 __global__ void io_loss_kernel(const float* __restrict__ parts, float* __restrict__ metrics, int I, int B, float beta) {
@@ -580,9 +637,12 @@ __global__ void io_loss_kernel(const float* __restrict__ parts, float* __restric
 
 // =========================================================================================== launchers
 #define IO_GRID(n) dim3(cdiv((n), 256)), dim3(256)
+// kl_out[0] = sum of the elementwise KL terms (written, not accumulated); ws: n floats of scratch
 int io_sample_launch(const float* mu, const float* ls, const float* noise, float* eps_out, float* slots, float* kl_out, long long n,
-                     unsigned long long seed, unsigned site, hipStream_t st) {
-    hipLaunchKernelGGL(io_sample_kernel, IO_GRID(n), 0, st, mu, ls, noise, eps_out, slots, kl_out, n, seed, site);
+                     unsigned long long seed, unsigned site, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(ws && ws_floats >= (size_t)n, "io_sample: scratch too small");
+    hipLaunchKernelGGL(io_sample_kernel, IO_GRID(n), 0, st, mu, ls, noise, eps_out, slots, ws, n, seed, site);
+    hipLaunchKernelGGL(io_ordered_sum_kernel, dim3(1), dim3(1024), 0, st, ws, n, 1ll, kl_out);
     OCRL_CHECK_LAUNCH("io_sample");
     return 0;
 }
@@ -606,8 +666,12 @@ int io_layer1_launch(const float* P1, const float* T, float* c1, long long BK, i
     OCRL_CHECK_LAUNCH("io_layer1");
     return 0;
 }
-int io_layer1_bwd_launch(const float* g, float* dT, long long BK, int S, hipStream_t st) {
-    hipLaunchKernelGGL(io_layer1_bwd_kernel, dim3((unsigned)(BK * S)), dim3(256), 0, st, g, dT, S);
+// dT [BK][9][64] is written (not accumulated); ws: BK*S*3*64 floats of scratch
+int io_layer1_bwd_launch(const float* g, float* dT, long long BK, int S, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(S >= 3 && ws && ws_floats >= (size_t)BK * S * 3 * 64, "io_layer1_bwd: S < 3 or scratch too small");
+    hipLaunchKernelGGL(io_layer1_bwd_kernel, dim3((unsigned)(BK * S)), dim3(256), 0, st, g, ws, S);
+    const long long n = BK * 9 * 64;
+    hipLaunchKernelGGL(io_layer1_reduce_kernel, IO_GRID(n), 0, st, ws, dT, n, S);
     OCRL_CHECK_LAUNCH("io_layer1_bwd");
     return 0;
 }
@@ -616,18 +680,29 @@ int io_w1_grad_launch(const float* dW1r, const float* G, float* dW1, float* db1,
     OCRL_CHECK_LAUNCH("io_w1_grad");
     return 0;
 }
+// st1 [B*K][4] is written when enc is given; part[0..1] += (log-likelihood, squared error) totals; ws: (B*S*S/256) * 66 floats of scratch
 int io_elbo_launch(const float* out4, const float* obs, int B, int K, int S, float sigma, float* enc, float* st1, float* dout4, float* part,
-                   float* masks_out, float* recon_out, float* rmasked_out, hipStream_t st) {
+                   float* masks_out, float* recon_out, float* rmasked_out, float* ws, size_t ws_floats, hipStream_t st) {
     OCRL_REQUIRE(K >= 1 && K <= 16 && (S * S) % 256 == 0, "iodine elbo: 1 <= K <= 16 and S %% 16 == 0 required (K=%d S=%d)", K, S);
-    const dim3 grid((unsigned)((long long)B * S * S / 256));
-    if (K <= 8) hipLaunchKernelGGL(io_elbo_kernel<8>, grid, dim3(256), 0, st, out4, obs, B, K, S, sigma, enc, st1, dout4, part, masks_out, recon_out, rmasked_out);
-    else hipLaunchKernelGGL(io_elbo_kernel<16>, grid, dim3(256), 0, st, out4, obs, B, K, S, sigma, enc, st1, dout4, part, masks_out, recon_out, rmasked_out);
+    const int nb_img = S * S / 256;
+    OCRL_REQUIRE(ws && ws_floats >= (size_t)B * nb_img * 66, "iodine elbo: scratch too small");
+    const dim3 grid((unsigned)((long long)B * nb_img));
+    if (K <= 8) {
+        hipLaunchKernelGGL(io_elbo_kernel<8>, grid, dim3(256), 0, st, out4, obs, B, K, S, sigma, enc, ws, dout4, masks_out, recon_out, rmasked_out);
+        hipLaunchKernelGGL(io_elbo_reduce_kernel<8>, dim3(1), dim3(256), 0, st, ws, st1, part, B, K, nb_img, enc ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL(io_elbo_kernel<16>, grid, dim3(256), 0, st, out4, obs, B, K, S, sigma, enc, ws, dout4, masks_out, recon_out, rmasked_out);
+        hipLaunchKernelGGL(io_elbo_reduce_kernel<16>, dim3(1), dim3(256), 0, st, ws, st1, part, B, K, nb_img, enc ? 1 : 0);
+    }
     OCRL_CHECK_LAUNCH("io_elbo");
     return 0;
 }
-int io_enc_norm_launch(float* enc, const float* st1, float* st2, long long BK, int N, hipStream_t st) {
+// st2 [BK][4] is written; ws: BK * N/256 * 4 floats of scratch
+int io_enc_norm_launch(float* enc, const float* st1, float* st2, long long BK, int N, float* ws, size_t ws_floats, hipStream_t st) {
     OCRL_REQUIRE(N % 256 == 0, "iodine encoding: S %% 16 == 0 required");
-    hipLaunchKernelGGL(io_enc_var_kernel, dim3((unsigned)(BK * N / 256)), dim3(256), 0, st, enc, st1, st2, N);
+    OCRL_REQUIRE(ws && ws_floats >= (size_t)BK * (N / 256) * 4, "iodine encoding: scratch too small");
+    hipLaunchKernelGGL(io_enc_var_kernel, dim3((unsigned)(BK * N / 256)), dim3(256), 0, st, enc, st1, ws, N);
+    hipLaunchKernelGGL(io_enc_var_reduce_kernel, IO_GRID(BK * 4), 0, st, ws, st2, BK * 4, N / 256);
     hipLaunchKernelGGL(io_enc_norm_kernel, dim3((unsigned)(BK * N / 256)), dim3(256), 0, st, enc, st1, st2, N);
     OCRL_CHECK_LAUNCH("io_enc_norm");
     return 0;
@@ -702,9 +777,11 @@ int io_post_grad_launch(const float* mu, const float* ls, const float* eps, cons
     OCRL_CHECK_LAUNCH("io_post_grad");
     return 0;
 }
-int io_l2norm_launch(const float* g, long long n, float* out, hipStream_t st) {
-    OCRL_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
-    hipLaunchKernelGGL(io_sumsq_kernel, dim3(1024), dim3(256), 0, st, g, n, out);
+// ws: 1024 floats of scratch
+int io_l2norm_launch(const float* g, long long n, float* out, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(ws && ws_floats >= 1024, "io_l2norm: scratch too small");
+    hipLaunchKernelGGL(io_sumsq_kernel, dim3(1024), dim3(256), 0, st, g, n, ws);
+    hipLaunchKernelGGL(io_ordered_sum_kernel, dim3(1), dim3(1024), 0, st, ws, 1024ll, 1ll, out);
     hipLaunchKernelGGL(io_sqrt_kernel, dim3(1), dim3(1), 0, st, out);
     OCRL_CHECK_LAUNCH("io_l2norm");
     return 0;

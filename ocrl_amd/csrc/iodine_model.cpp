@@ -78,6 +78,8 @@ void IodineModel::layout_workspace(bool commit) {
         if (sk > need) need = sk;
         const size_t cs = (size_t)N * 64 * 4 + (1 << 20);
         if (cs > need) need = cs;
+        const size_t rp = BK * (size_t)S * 3 * 64;        // row partials of the first decoder layer's backward
+        if (rp > need) need = rp;
         scratch_floats_ = need + (1 << 20);
     }
     scratch_ = carve(nullptr, scratch_floats_);
@@ -241,8 +243,7 @@ int IodineModel::decoder_bwd(int i, const float* dout4, bool weights, hipStream_
         float* t = cur; cur = nxt; nxt = t;
     }
     // first layer through the broadcast shortcut (cur = d pre-activation of layer 0)
-    RC(fill_launch(T_, BK * 576, 0.f, st));
-    RC(io_layer1_bwd_launch(cur, T_, BK, S, st));
+    RC(io_layer1_bwd_launch(cur, T_, BK, S, scratch_, scratch_floats_, st));
     RC(io_class_sum_launch(T_, M_, BK, 0, st));
     RC(gemm_nn(M_, 576, W1r_, L, dslots_, L, BK, 576, L, nullptr, 0, st));
     if (weights) {
@@ -292,15 +293,13 @@ int IodineModel::forward(const float* obs, int B, unsigned long long seed, const
     for (int i = 0; i < I; ++i) {
         const bool last = i == I - 1;
         RC(io_sample_launch(mu_[i], ls_[i], noise ? noise + (size_t)i * BK * L : nullptr, eps_[i], slots_[i], parts_ + i * 4 + 2, BK * L, seed,
-                            300u + (unsigned)i, st));
+                            300u + (unsigned)i, scratch_, scratch_floats_, st));
         RC(decoder_fwd(i, st));
-        if (!last) RC(fill_launch(st1_, BK * 4, 0.f, st));
         RC(io_elbo_launch(out4_[i], obs, B, K, S, cfg.sigma, last ? nullptr : enc_[i], st1_, last ? nullptr : dout4_, parts_ + i * 4,
-                          last ? masks_ : nullptr, last ? recon_ : nullptr, last ? rmasked_ : nullptr, st));
+                          last ? masks_ : nullptr, last ? recon_ : nullptr, last ? rmasked_ : nullptr, scratch_, scratch_floats_, st));
         if (last) break;
         if (cfg.layer_norm) {
-            RC(fill_launch(st2_, BK * 4, 0.f, st));
-            RC(io_enc_norm_launch(enc_[i], st1_, st2_, BK, N, st));
+            RC(io_enc_norm_launch(enc_[i], st1_, st2_, BK, N, scratch_, scratch_floats_, st));
         }
         RC(decoder_bwd(i, dout4_, false, st));                                  // d(B*elbo)/d slots
         RC(io_latent_launch(mu_[i], ls_[i], eps_[i], dslots_, xin_[i] + Hm, BK, L, cfg.beta, cfg.layer_norm, XW, st));
@@ -378,7 +377,7 @@ int IodineModel::backward(hipStream_t st) {
     return 0;
 }
 
-int IodineModel::grad_norm(hipStream_t st) { return io_l2norm_launch(g_, flat_size_, metrics_ + 3, st); }
+int IodineModel::grad_norm(hipStream_t st) { return io_l2norm_launch(g_, flat_size_, metrics_ + 3, scratch_, scratch_floats_, st); }
 
 // clip_grad_norm_(params, clip, 2.0) + Adam over the one parameter group (ocrs/base.py:60-74).  `slot_init` never receives a
 // gradient in the reference, so torch's Adam skips it: the update covers the two ranges around it.

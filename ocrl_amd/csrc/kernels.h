@@ -217,16 +217,16 @@ int bc_mix_launch(const float* out4, const float* obs, float* recon, float* dout
 
 // ------------------------------------------------------------------ iodine.hip (IODINE: ocrs/iodine/iodine_module.py)
 int io_sample_launch(const float* mu, const float* ls, const float* noise, float* eps_out, float* slots, float* kl_out, long long n,
-                     unsigned long long seed, unsigned site, hipStream_t st);
+                     unsigned long long seed, unsigned site, float* ws, size_t ws_floats, hipStream_t st);
 int io_w1_pack_launch(const float* W1, float* W1r, float* Wxy, int L, hipStream_t st);
 int io_p1_launch(const float* Wxy, const float* b1, float* P1, int S, hipStream_t st);
 int io_class_sum_launch(const float* in, float* out, long long BK, int forward, hipStream_t st);
 int io_layer1_launch(const float* P1, const float* T, float* c1, long long BK, int S, hipStream_t st);
-int io_layer1_bwd_launch(const float* g, float* dT, long long BK, int S, hipStream_t st);
+int io_layer1_bwd_launch(const float* g, float* dT, long long BK, int S, float* ws, size_t ws_floats, hipStream_t st);
 int io_w1_grad_launch(const float* dW1r, const float* G, float* dW1, float* db1, int S, int L, hipStream_t st);
 int io_elbo_launch(const float* out4, const float* obs, int B, int K, int S, float sigma, float* enc, float* st1, float* dout4, float* part,
-                   float* masks_out, float* recon_out, float* rmasked_out, hipStream_t st);
-int io_enc_norm_launch(float* enc, const float* st1, float* st2, long long BK, int N, hipStream_t st);
+                   float* masks_out, float* recon_out, float* rmasked_out, float* ws, size_t ws_floats, hipStream_t st);
+int io_enc_norm_launch(float* enc, const float* st1, float* st2, long long BK, int N, float* ws, size_t ws_floats, hipStream_t st);
 int io_elbo_bwd_launch(const float* out4, const float* obs, const float* denc, int B, int K, int S, float sigma, float cw, float* dout4, hipStream_t st);
 int io_latent_launch(const float* mu, const float* ls, const float* eps, const float* ds, float* latent, long long BK, int L, float beta, int layer_norm,
                      int ld, hipStream_t st);
@@ -242,5 +242,5 @@ int io_lstm_bwd_launch(const float* acts, const float* c0, const float* c1, cons
                        long long rows, int H, hipStream_t st);
 int io_post_grad_launch(const float* mu, const float* ls, const float* eps, const float* ds, const float* dlat, int ldl, float kw, float* gmu,
                         float* gls, long long BK, int L, hipStream_t st);
-int io_l2norm_launch(const float* g, long long n, float* out, hipStream_t st);
+int io_l2norm_launch(const float* g, long long n, float* out, float* ws, size_t ws_floats, hipStream_t st);
 int io_loss_launch(const float* parts, float* metrics, int I, int B, float beta, hipStream_t st);

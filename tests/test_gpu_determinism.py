@@ -46,3 +46,35 @@ def test_two_runs_are_bitwise_identical(tag, over, B):
         assert torch.equal(m1[:4], m2[:4]), (tag, step, m1, m2)
         assert torch.equal(g1, g2), (tag, step, int((g1 != g2).sum()), float((g1 - g2).abs().max()))
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+def test_iodine_two_runs_are_bitwise_identical():
+    """IODINE (BASELINE config 4's slot / iteration counts at 32x32): forward with the device RNG, backward, L2 clip + Adam, three steps"""
+    from oracle import iodine_oracle as IO
+    from tests.test_gpu_iodine import dims
+    from ocrl_amd.engine import IodineEngine
+    cfg = IO.default_cfg(obs_size=32, num_slots=7, num_iterations=5)
+    B = 3
+    P = IO.formula_params(cfg)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(2)).cuda()
+    runs = []
+    for _ in range(2):
+        eng = IodineEngine(dims(cfg), max_batch=B)
+        load_params(eng, P)
+        trace = []
+        for step in range(3):
+            eng.forward(obs, seed=50 + step)
+            eng.backward()
+            torch.cuda.synchronize()
+            g = eng.flat_g.cpu().clone()
+            eng.clip_adam(cfg.lr, cfg.clip)
+            trace.append((eng.metrics.cpu().clone(), g))
+        torch.cuda.synchronize()
+        runs.append((trace, eng.flat_p.cpu().clone()))
+        del eng
+    (ta, pa), (tb, pb) = runs
+    for step, ((m1, g1), (m2, g2)) in enumerate(zip(ta, tb)):
+        assert torch.isfinite(g1).all()
+        assert torch.equal(m1[:4], m2[:4]), (step, m1, m2)
+        assert torch.equal(g1, g2), (step, int((g1 != g2).sum()), float((g1 - g2).abs().max()))
+    assert torch.equal(pa, pb)
