@@ -851,8 +851,9 @@ __global__ __launch_bounds__(SA_TB) void sa_slot_bwd_kernel(SlotAttnArgs p, SaWt
     for (int i = tid; i < SM; i += nt) gs[i] = L.gacc[i];
     for (int i = tid; i < (nimg - 1) * SM; i += nt) gs[SM + i] = 0.f;
 }
+// 2 workgroups per CU = 256 VGPRs: at 3 (170 VGPRs) the FINAL variant spills 12 registers and the backward chain is 86 us slower
 template <int K, bool FIRST, bool FINAL>
-__global__ __launch_bounds__(SA_TS, 3) void sa_stream_bwd_kernel(SlotAttnArgs p, int NS) {
+__global__ __launch_bounds__(SA_TS, 2) void sa_stream_bwd_kernel(SlotAttnArgs p, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int C = SA_C, KP = SaBlk<K>::KP;
     const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
