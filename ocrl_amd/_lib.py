@@ -27,6 +27,10 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C ocrl_amd/csrc).  ocrl_amd has no CPU fallback.")
+    # PyTorch-ROCm carries its own copy of the HIP runtime; it has to be the one already in the process when this library resolves its
+    # libamdhip64 dependency, or the two halves talk to two runtimes (observed: "no ROCm-capable device is detected" from the library
+    # when it was loaded before torch)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     p = c_void_p
     L.ocrl_last_error.restype = c_char_p
