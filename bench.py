@@ -141,6 +141,19 @@ def timed_region(args, dev, dist, step_fn, prof_mask):
     return dt, list(ms), list(cnt), last
 
 
+def committed_slot_attention_pmc(B, S):
+    """matrix-pipe busy fraction, resident waves and HBM bytes per launch of the slot-attention kernels from this round's committed
+    rocprofv3 PMC passes over this same command (profiles/r02_pmc_slot_attention.json); None when measured at another shape"""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_slot_attention.json")))
+        if pj.get("batch") == B and pj.get("obs_size") == S:
+            return {"source": "profiles/r02_pmc_slot_attention.json (build %s)" % pj.get("build"),
+                    **{k.replace("void ", ""): {q: (round(v, 3) if isinstance(v, float) and v < 100 else int(v)) for q, v in d.items()} for k, d in pj["kernels"].items()}}
+    except Exception:
+        pass
+    return None
+
+
 def slot_attention_standalone(B, N, K, iters=10):
     """the north-star kernel chain on its own (include/ocrl_hip.h ocrl_slot_attention_fwd/bwd, same code path as the model), timed with
     HIP events around the streaming + slot-side launches only: inside the step its forward shares the GPU with the dVAE branch
@@ -362,9 +375,10 @@ def main():
                                  "fwd": leg(sf_ms, fwd_bytes), "bwd": leg(sb_ms, bwd_bytes),
                                  "in_step": {"fwd": leg(ms[4] / cnt[4], fwd_bytes), "bwd": leg(ms[5] / cnt[5], bwd_bytes),
                                              "note": "inside the step the forward chain shares the GPU with the dVAE branch on the side stream (OCRL_OVERLAP)"},
+                                 "pmc": committed_slot_attention_pmc(B, S),
                                  "note": "algorithmic bytes of the folded-projection form (12.6 MB/img forward, 33.5 MB/img backward at N=16384; the reference's "
                                          "materialised k|v form would move 75.5 MB/img forward); fwd / bwd = the chain on its own at the same shape, HIP events "
-                                         "around its launches; MFMA-busy / HBM PMC counters: profiles/r02_pmc_*"}
+                                         "around its launches; pmc = matrix-pipe busy fraction / resident waves per SIMD / HBM bytes per launch from rocprofv3 counters"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec))
     if args.rehearse_on_one_gpu:
