@@ -38,24 +38,24 @@ void ocrl_set_error(const char* fmt, ...);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// ---- counter-based RNG (Philox-2x32, 7 rounds): stateless, so forward and backward
-//      regenerate the same dropout decisions without storing masks.
-__host__ __device__ inline uint2 philox2x32(uint32_t c0, uint32_t c1, uint32_t key) {
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        const uint64_t p = (uint64_t)c0 * 0xD256D193u;
-        const uint32_t hi = (uint32_t)(p >> 32), lo = (uint32_t)p;
-        c0 = hi ^ key ^ c1;
-        c1 = lo;
-        key += 0x9E3779B9u;
-    }
-    return make_uint2(c0, c1);
+// ---- counter-based RNG: stateless, so forward and backward regenerate the same dropout decisions without storing masks.
+// 64 bits per call from two passes of a 32-bit avalanche mixer (two multiplies and three xor-shifts each; the "lowbias32" constants,
+// bias 0.17 %) over the element counter xor a per-(seed, site) key.  Round 1 used Philox-2x32-7 (14 quarter-rate integer multiplies per
+// call); this form needs 4 (measured: +0.4 % images/s — the Gumbel kernel turned out to be bound by its logs and exp, not the draws).
+// tests/test_gpu_determinism.py::test_device_rng_quality checks rates, serial and cross-site / cross-seed correlations.
+__host__ __device__ inline uint32_t rng_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 
 // 64 random bits for the group of four consecutive elements idx4 = element_index / 4 at `site`.
 __host__ __device__ inline uint2 rng_bits4(uint64_t seed, uint32_t site, uint64_t idx4) {
-    const uint32_t key = (uint32_t)seed ^ (site * 0x85EBCA6Bu) ^ (uint32_t)(idx4 >> 32) * 0xC2B2AE35u;
-    return philox2x32((uint32_t)idx4, (uint32_t)(seed >> 32) ^ site, key);
+    // key: uniform over a launch (scalar work); the high counter bits enter here so that >2^32 groups do not repeat
+    const uint32_t key = rng_mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ rng_mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu * ((uint32_t)(idx4 >> 32) + 1u));
+    const uint32_t c = (uint32_t)idx4 ^ key;
+    return make_uint2(rng_mix32(c), rng_mix32(c ^ 0x68E31DA4u) + key);
 }
 
 // keep decision for element e (0..3) of a group: 16-bit uniform >= thresh, thresh = round(p * 65536)

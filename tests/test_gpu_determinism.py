@@ -78,3 +78,30 @@ def test_iodine_two_runs_are_bitwise_identical():
         assert torch.equal(m1[:4], m2[:4]), (step, m1, m2)
         assert torch.equal(g1, g2), (step, int((g1 != g2).sum()), float((g1 - g2).abs().max()))
     assert torch.equal(pa, pb)
+
+
+def test_device_rng_quality():
+    """the counter RNG behind dropout / Gumbel / slot noise (csrc/common.h rng_bits4): keep rates per element slot, serial correlation,
+    independence across sites and seeds, on the dumped keep-masks of 2^21 elements"""
+    import ctypes
+    from ocrl_amd import _lib
+    from ocrl_amd.engine import SlateEngine
+    cfg = O.default_cfg(obs_size=16, vocab_size=256, num_slots=3, num_iterations=1, num_dec_blocks=1)
+    eng = SlateEngine(dims_from_cfg(cfg), max_batch=1)
+    load_params(eng, O.formula_params(cfg))
+    obs = torch.rand(1, 3, 16, 16, device="cuda")
+    n = 1 << 21
+
+    def masks(seed, site):
+        eng.forward(obs, 1.0, train=True, seed=seed)        # sets the step's seed and dropout probability (0.1)
+        return eng.dropout_mask(site, (n,)).cpu().double()
+
+    a, b, c = masks(11, 17), masks(11, 18), masks(12, 17)
+    for m in (a, b, c):
+        assert abs(m.mean().item() - 0.9) < 2e-3, m.mean()
+        for e in range(4):                                  # the four elements of a 64-bit draw
+            assert abs(m[e::4].mean().item() - 0.9) < 3e-3, (e, m[e::4].mean())
+    corr = lambda x, y: float(((x - x.mean()) * (y - y.mean())).mean() / (x.std() * y.std()))
+    assert abs(corr(a[:-1], a[1:])) < 4e-3 and abs(corr(a[:-4], a[4:])) < 4e-3 and abs(corr(a[:-64], a[64:])) < 4e-3      # serial
+    assert abs(corr(a, b)) < 4e-3 and abs(corr(a, c)) < 4e-3                                                                   # site / seed
+    assert not torch.equal(a, b) and not torch.equal(a, c)
