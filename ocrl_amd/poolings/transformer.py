@@ -39,6 +39,70 @@ class _PositionalEncoding(nn.Module):
         self.register_buffer("pe", pe)
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = [relu](x W^T + b) on rows, forward and backward through the library's MFMA GEMM (include/ocrl_hip.h ocrl_gemm: NT with fused
+    bias / ReLU, NN with the ReLU mask for dx, TN for dW) — the slot MLPs in front of the pooling transformer (transformer_module.py:47-63)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        if not x.is_cuda:
+            raise RuntimeError("ocrl_amd.poolings: tensors must live on the GPU (there is no CPU fallback)")
+        L = _lib.lib()
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous().float()
+        M, K = x2.shape
+        N = weight.shape[0]
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.ocrl_gemm(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(y), M, N, K, K, K, N, 1, 1, 1.0, _lib.ptr(b), int(relu), None, 0, None, 0, 1, None, st))
+        ctx.save_for_backward(x2, w, y)
+        ctx.relu, ctx.shape = bool(relu), shp
+        return y.reshape(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x2, w, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(M, N).contiguous().float()
+        if ctx.relu:
+            dy2 = dy2 * (y > 0)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)           # dx = dy W        (NN)
+            _lib.check(L.ocrl_gemm(_lib.ptr(dy2), _lib.ptr(w), _lib.ptr(dx), M, K, N, N, K, K, 1, 0, 1.0, None, 0, None, 0, None, 0, 1, None, st))
+            dx = dx.reshape(ctx.shape)
+        dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)               # dW = dy^T x     (TN over the rows)
+        _lib.check(L.ocrl_gemm(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(dw), N, K, M, N, K, K, 0, 0, 1.0, None, 0, None, 0, None, 0, 1, None, st))
+        return dx, dw, dy2.sum(0), None
+
+
+class _HipLinear(nn.Linear):
+    """nn.Linear container (reference names / initialisation) whose arithmetic runs on the library's GEMM"""
+
+    def __init__(self, i, o, relu=False):
+        super().__init__(i, o)
+        self._relu = relu
+
+    def forward(self, x):
+        return _LinearFn.apply(x, self.weight, self.bias, self._relu)
+
+
+def _slot_mlp(widths):
+    """nn.Sequential(Linear, ReLU, Linear[, ReLU, Linear]) with the reference's indices (the ReLUs are fused into the products, their
+    slots are kept as Identity so that state_dict keys stay mlp.0 / mlp.2 / mlp.4)"""
+    layers = []
+    for k in range(len(widths) - 1):
+        last = k == len(widths) - 2
+        layers.append(_HipLinear(widths[k], widths[k + 1], relu=not last))
+        if not last:
+            layers.append(nn.Identity())
+    return nn.Sequential(*layers)
+
+
 class _PoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, slots, pos, geom, drop_p, seed, *params):
@@ -91,9 +155,16 @@ class Transformer_Module(nn.Module):
         super().__init__()
         self.rep_dim = d_model = config.d_model
         self.config = config
-        for flag in ("use_mlp1", "use_mlp2", "cw_embedding", "push_embedding"):
+        for flag in ("cw_embedding", "push_embedding"):        # embeddings of ground-truth state vectors (ocr=GT): not an image path
             if getattr(config, flag, False):
-                raise NotImplementedError(f"pooling.{flag}=True is not built in this backend (transformer_module.py:47-78)")
+                raise NotImplementedError(f"pooling.{flag}=True is not built in this backend (transformer_module.py:65-78)")
+        self.mlp = None
+        if getattr(config, "use_mlp1", False):                  # transformer_module.py:47-53
+            self.mlp = _slot_mlp([ocr_rep_dim, 64, 128])
+            ocr_rep_dim = 128
+        if getattr(config, "use_mlp2", False):                  # transformer_module.py:55-63 (replaces mlp1's module when both are set, as in the reference)
+            self.mlp = _slot_mlp([ocr_rep_dim, 64, 64, 128])
+            ocr_rep_dim = 128
         if num_stacked_obss > 1:
             pos = _PositionalEncoding(ocr_num_slots * num_stacked_obss + 1, d_model, num_stacked_obss)
         elif config.pos_emb in ("ape", "lpe"):           # both map to the fixed table in the reference (transformer_module.py:40-43)
@@ -118,6 +189,8 @@ class Transformer_Module(nn.Module):
         return ps
 
     def forward(self, state):
+        if self.mlp is not None:                                # transformer_module.py:103-104
+            state = self.mlp(state)
         pos = None if self._trans._pos is None else self._trans._pos.pe[: state.shape[1] + 1, 0].contiguous()
         p = self._drop_p if self.training else 0.0
         self._calls += 1

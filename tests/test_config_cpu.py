@@ -130,4 +130,10 @@ def test_pooling_module_mirrors_reference_state_dict():
         with pytest.raises(RuntimeError):
             m(torch.zeros(2, cfg.num_slots, cfg.rep_dim))
     with pytest.raises(NotImplementedError):
-        Transformer_Module(64, 4, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", use_mlp1=True))
+        Transformer_Module(64, 4, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", cw_embedding=True))
+    # use_mlp1 / use_mlp2 (transformer_module.py:47-63): the slot MLP's keys and shapes are the reference nn.Sequential's
+    m1 = Transformer_Module(192, 6, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", use_mlp1=True))
+    assert [(k, tuple(v.shape)) for k, v in m1.state_dict().items()][:4] == [("mlp.0.weight", (64, 192)), ("mlp.0.bias", (64,)), ("mlp.2.weight", (128, 64)), ("mlp.2.bias", (128,))]
+    assert tuple(m1.state_dict()["_trans._linear.weight"].shape) == (128, 128)
+    m2 = Transformer_Module(192, 6, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", use_mlp2=True))
+    assert [k for k in m2.state_dict() if k.startswith("mlp.")] == ["mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias"]

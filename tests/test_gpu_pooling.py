@@ -195,3 +195,37 @@ def test_pooling_wrapper_and_extractor_over_the_encoder():
     ex.eval()
     f = ex(obs)
     assert f.shape == (4, ex.features_dim) and torch.isfinite(f).all()
+
+
+@pytest.mark.parametrize("flag,widths", [("use_mlp1", [192, 64, 128]), ("use_mlp2", [192, 64, 64, 128])])
+def test_slot_mlp_switches(flag, widths):
+    """pooling.use_mlp1 / use_mlp2 (poolings/transformer/transformer_module.py:47-63,103-104): the slot MLP in front of the transformer runs
+    on the library's GEMM; forward and every MLP gradient against the same chain in fp64 torch around the (separately verified) transformer"""
+    from ocrl_amd.poolings import Transformer_Module
+    B, K = 5, 6
+    base = dict(d_model=128, nhead=8, num_layers=1, pos_emb="None", norm_first=False, use_mlp1=False, use_mlp2=False, cw_embedding=False, push_embedding=False)
+    torch.manual_seed(3)
+    m = Transformer_Module(192, K, types.SimpleNamespace(**{**base, flag: True})).cuda().eval()
+    plain = Transformer_Module(128, K, types.SimpleNamespace(**base)).cuda().eval()
+    plain._trans.load_state_dict(m._trans.state_dict())
+    slots = torch.randn(B, K, 192, generator=torch.Generator().manual_seed(4))
+    # fp64 chain of the reference nn.Sequential with the module's weights
+    ws = [(m.mlp[2 * i].weight.detach().double().cpu().requires_grad_(True), m.mlp[2 * i].bias.detach().double().cpu().requires_grad_(True)) for i in range(len(widths) - 1)]
+    x = slots.double()
+    for i, (w, b) in enumerate(ws):
+        x = x @ w.T + b
+        if i < len(ws) - 1:
+            x = torch.relu(x)
+    y_in = x.detach().float().cuda().requires_grad_(True)
+    out_ref = plain(y_in)
+    out = m(slots.cuda())
+    e_out = relerr(out, out_ref)
+    dout = torch.randn(B, 128, generator=torch.Generator().manual_seed(5)).cuda()
+    out.backward(dout)
+    out_ref.backward(dout)
+    x.backward(y_in.grad.double().cpu())
+    errs = [e_out]
+    for i, (w, b) in enumerate(ws):
+        errs += [relerr(m.mlp[2 * i].weight.grad, w.grad), relerr(m.mlp[2 * i].bias.grad, b.grad)]
+    log(f"[pooling {flag}] output {e_out:.2e}; MLP weight / bias gradients worst {max(errs[1:]):.2e}")
+    assert max(errs) < 3e-4, errs
