@@ -617,7 +617,6 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
                                                              int h, float p, unsigned long long seed, unsigned site) {
     extern __shared__ float sm[];   // Ks [K][dh], Vs [K][dh], stage [4][64][CA_SW]
     constexpr int CA_SW = CA_MAXK + CA_MAXDH + 1;
-    constexpr int NACC = CA_MAXK * CA_MAXDH / 64;          // slot-side outputs per lane
     float* mypart = part + (size_t)blockIdx.x * 2 * K * (d / h);
     const int dh = d / h;
     const int nqb = (T + 255) / 256;
@@ -683,20 +682,28 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     for (int c = 0; c < CA_MAXDH; ++c)
         if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = go[c];
     __syncthreads();
-    float av[NACC];
+    // [slots x 64 queries] . [64 queries x dh] on the matrix cores: slots on the 16 MFMA rows, 16-channel tiles on the columns, four
+    // queries per v_mfma_f32_16x16x4_f32 (lane (li, g): A = stage[query 4s+g][slot li], B = stage[query 4s+g][channel 16m+li])
+    const int li = lane & 15, g4 = lane >> 4, nmt = (dh + 15) >> 4;
+    f32x4 acc[CA_MAXDH / 16];
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const int o = lane + 64 * i;
-        float a = 0.f;
-        if (o < K * dh) {
-            const int k = o / dh, c = o - k * dh;
-            for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
-        }
-        av[i] = a;
+    for (int m = 0; m < CA_MAXDH / 16; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s16 = 0; s16 < 16; ++s16) {
+        const float* rowp = stg + (4 * s16 + g4) * CA_SW;
+        const float a = li < CA_MAXK ? rowp[li] : 0.f;
+#pragma unroll
+        for (int m = 0; m < CA_MAXDH / 16; ++m)
+            if (m < nmt) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rowp[CA_MAXK + 16 * m + li], acc[m], 0, 0, 0);
     }
     __syncthreads();                                       // every wave is done reading its staging tile
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) stg[lane + 64 * i] = av[i];
+    for (int m = 0; m < CA_MAXDH / 16; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g4 + r, c = 16 * m + li;
+            if (m < nmt && k < K && c < dh) stg[k * dh + c] = acc[m][r];
+        }
     __syncthreads();
     for (int o = threadIdx.x; o < K * dh; o += 256) {
         const float* r = sm + 2 * K * dh + o;
@@ -722,18 +729,23 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
         if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = qv[c];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const int o = lane + 64 * i;
-        float a = 0.f;
-        if (o < K * dh) {
-            const int k = o / dh, c = o - k * dh;
-            for (int qq = 0; qq < 64; ++qq) a += stg[qq * CA_SW + k] * stg[qq * CA_SW + CA_MAXK + c];
-        }
-        av[i] = a;
+    for (int m = 0; m < CA_MAXDH / 16; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s16 = 0; s16 < 16; ++s16) {
+        const float* rowp = stg + (4 * s16 + g4) * CA_SW;
+        const float a = li < CA_MAXK ? rowp[li] : 0.f;
+#pragma unroll
+        for (int m = 0; m < CA_MAXDH / 16; ++m)
+            if (m < nmt) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, rowp[CA_MAXK + 16 * m + li], acc[m], 0, 0, 0);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) stg[lane + 64 * i] = av[i];
+    for (int m = 0; m < CA_MAXDH / 16; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g4 + r, c = 16 * m + li;
+            if (m < nmt && k < K && c < dh) stg[k * dh + c] = acc[m][r];
+        }
     __syncthreads();
     for (int o = threadIdx.x; o < K * dh; o += 256) {
         const float* r = sm + 2 * K * dh + o;
