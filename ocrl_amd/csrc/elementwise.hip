@@ -569,8 +569,11 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
         if (k < K) {
             float a = 0.f;
 #pragma unroll
-            for (int c = 0; c < CA_MAXDH; ++c)
-                if (c < dh) a += qv[c] * Ks[k * dh + c];
+            for (int c = 0; c < CA_MAXDH; c += 4)              // broadcast ds_read_b128: a quarter of the LDS instructions
+                if (c < dh) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(Ks + k * dh + c);
+                    a += (qv[c] * k4.x + qv[c + 1] * k4.y) + (qv[c + 2] * k4.z + qv[c + 3] * k4.w);
+                }
             s[k] = a;
             mx = fmaxf(mx, a);
         }
@@ -596,8 +599,11 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
                 pd = rng_keep(rng_bits4(seed, site, idx >> 2), (int)(idx & 3), thr) ? pr * sc : 0.f;
             }
 #pragma unroll
-            for (int c = 0; c < CA_MAXDH; ++c)
-                if (c < dh) o[c] += pd * Vs[k * dh + c];
+            for (int c = 0; c < CA_MAXDH; c += 4)
+                if (c < dh) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(Vs + k * dh + c);
+                    o[c] += pd * v4.x; o[c + 1] += pd * v4.y; o[c + 2] += pd * v4.z; o[c + 3] += pd * v4.w;
+                }
         }
     float* op = O + (b * T + q) * d + hd * dh;
 #pragma unroll
@@ -637,23 +643,29 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     const int q = qb * 256 + threadIdx.x;
     const bool act = q < T;
     const float scale = rsqrtf((float)dh);
-    float qv[CA_MAXDH], go[CA_MAXDH];
+    // The wave's 64 query rows of dO (and later of Q) are fetched as one coalesced tile (consecutive lanes = consecutive 16 bytes of a
+    // row) straight into the staging tile the matrix products read; a thread then takes its own row from LDS.  Thread-per-row global
+    // loads (64 different cache lines per instruction) were what bound this kernel.
+    const int q0 = qb * 256 + wv * 64, dh4 = dh >> 2;
+    auto load_tile = [&](const float* src, float mul) {
+        for (int idx = lane; idx < 64 * dh4; idx += 64) {
+            const int r = idx / dh4, c4 = idx - r * dh4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + r < T) v = *reinterpret_cast<const float4*>(src + (b * T + q0 + r) * d + hd * dh + 4 * c4);
+            float* dst = stg + r * CA_SW + CA_MAXK + 4 * c4;
+            dst[0] = v.x * mul; dst[1] = v.y * mul; dst[2] = v.z * mul; dst[3] = v.w * mul;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    load_tile(dO, 1.f);
+    float go[CA_MAXDH];
     float pr[CA_MAXK], dp[CA_MAXK], keepv[CA_MAXK];
 #pragma unroll
-    for (int c = 0; c < CA_MAXDH; ++c) { qv[c] = 0.f; go[c] = 0.f; }
+    for (int c = 0; c < CA_MAXDH; ++c) go[c] = c < dh ? stg[lane * CA_SW + CA_MAXK + c] : 0.f;
 #pragma unroll
     for (int k = 0; k < CA_MAXK; ++k) { pr[k] = 0.f; dp[k] = 0.f; keepv[k] = 0.f; }
     float delta = 0.f;
     if (act) {
-        const float* qp = Q + (b * T + q) * d + hd * dh;
-        const float* gp = dO + (b * T + q) * d + hd * dh;
-#pragma unroll
-        for (int c = 0; c < CA_MAXDH; c += 4)
-            if (c < dh) {
-                const float4 a = *reinterpret_cast<const float4*>(qp + c), g = *reinterpret_cast<const float4*>(gp + c);
-                qv[c] = a.x * scale; qv[c + 1] = a.y * scale; qv[c + 2] = a.z * scale; qv[c + 3] = a.w * scale;
-                go[c] = g.x; go[c + 1] = g.y; go[c + 2] = g.z; go[c + 3] = g.w;
-            }
         const uint32_t thr = drop_thresh(p);
         const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.f;
         const long long prow = ((b * h + hd) * T + q) * K;
@@ -669,18 +681,18 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
                 keepv[k] = keep;
                 float a = 0.f;
 #pragma unroll
-                for (int c = 0; c < CA_MAXDH; ++c)
-                    if (c < dh) a += go[c] * Vs[k * dh + c];
+                for (int c = 0; c < CA_MAXDH; c += 4)          // one broadcast ds_read_b128 per four channels (the per-channel form waited on 576 LDS reads per query)
+                    if (c < dh) {
+                        const float4 v4 = *reinterpret_cast<const float4*>(Vs + k * dh + c);
+                        a += (go[c] * v4.x + go[c + 1] * v4.y) + (go[c + 2] * v4.z + go[c + 3] * v4.w);
+                    }
                 dp[k] = a * keep;
                 delta += pr[k] * dp[k];
             }
     }
-    // ---- dV[k][c] += sum_q pd[q][k] * go[q][c]
+    // ---- dV[k][c] += sum_q pd[q][k] * go[q][c]      (go is already in the staging tile)
 #pragma unroll
     for (int k = 0; k < CA_MAXK; ++k) stg[lane * CA_SW + k] = pr[k] * keepv[k];
-#pragma unroll
-    for (int c = 0; c < CA_MAXDH; ++c)
-        if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = go[c];
     __syncthreads();
     // [slots x 64 queries] . [64 queries x dh] on the matrix cores: slots on the 16 MFMA rows, 16-channel tiles on the columns, four
     // queries per v_mfma_f32_16x16x4_f32 (lane (li, g): A = stage[query 4s+g][slot li], B = stage[query 4s+g][channel 16m+li])
@@ -720,13 +732,14 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
         stg[lane * CA_SW + k] = ds;
         if (k < K) {
 #pragma unroll
-            for (int c = 0; c < CA_MAXDH; ++c)
-                if (c < dh) dq[c] += ds * Ks[k * dh + c];
+            for (int c = 0; c < CA_MAXDH; c += 4)
+                if (c < dh) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(Ks + k * dh + c);
+                    dq[c] += ds * k4.x; dq[c + 1] += ds * k4.y; dq[c + 2] += ds * k4.z; dq[c + 3] += ds * k4.w;
+                }
         }
     }
-#pragma unroll
-    for (int c = 0; c < CA_MAXDH; ++c)
-        if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = qv[c];
+    load_tile(Q, scale);                                   // q' = scale * q of the wave's rows, straight into the staging tile
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < CA_MAXDH / 16; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -751,11 +764,17 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
         const float* r = sm + 2 * K * dh + o;
         mypart[K * dh + o] = (r[0] + r[64 * CA_SW]) + (r[2 * 64 * CA_SW] + r[3 * 64 * CA_SW]);
     }
-    if (act) {
-        float* dqp = dQ + (b * T + q) * d + hd * dh;
+    __syncthreads();                                       // the partials are out: the staging tile carries dQ to a coalesced store
 #pragma unroll
-        for (int c = 0; c < CA_MAXDH; c += 4)
-            if (c < dh) *reinterpret_cast<float4*>(dqp + c) = make_float4(dq[c] * scale, dq[c + 1] * scale, dq[c + 2] * scale, dq[c + 3] * scale);
+    for (int c = 0; c < CA_MAXDH; ++c)
+        if (c < dh) stg[lane * CA_SW + CA_MAXK + c] = dq[c] * scale;
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < 64 * dh4; idx += 64) {
+        const int r = idx / dh4, c4 = idx - r * dh4;
+        if (q0 + r < T) {
+            const float* src = stg + r * CA_SW + CA_MAXK + 4 * c4;
+            *reinterpret_cast<float4*>(dQ + (b * T + q0 + r) * d + hd * dh + 4 * c4) = make_float4(src[0], src[1], src[2], src[3]);
+        }
     }
 }
 
