@@ -81,6 +81,11 @@ float* ocrl_slate_metrics(const ocrl_slate* h);
  * (int32) [B,T], "zraw"/"z" [B,T,V], "feats" [B,N,64], "dec_out" [B,T,d], "pred", "mem", "emb",
  * "slots0", "sa_inputs") or any parameter name; count = capacity in elements at max_batch. */
 int ocrl_slate_tensor(const ocrl_slate* h, const char* name, float** ptr, long long* count);
+/* The soft Gumbel sample z = softmax((logits + g) / tau) of the last forward (ocrs/slate/slate_module.py:126, the `z` that
+ * get_loss(with_rep=True) returns, :239-241) written into the named tensor "z".  The training step itself never materialises it:
+ * the vocabulary products rebuild it from the stored scores ("zraw") and their row log-sum-exp ("z_lse").  Call between forward and
+ * backward; a no-op for hard=True models, whose forward writes "z" / "z_st" itself. */
+int ocrl_slate_soft_z(ocrl_slate* h, void* stream);
 /* The keep-mask (float 0/1) the kernels used for a dropout site in the last forward; site ids:
  * 1 = z_pos, 16 + 8*block + {0 self.attn, 1 self.out, 2 cross.attn, 3 cross.out, 4 ffn}. */
 int ocrl_slate_dropout_mask(const ocrl_slate* h, unsigned site, long long n, float* out, void* stream);

@@ -58,6 +58,7 @@ def lib():
     L.ocrl_slate_metrics.restype = p
     L.ocrl_slate_tensor.argtypes = [p, c_char_p, POINTER(p), POINTER(c_longlong)]
     L.ocrl_slate_dropout_mask.argtypes = [p, c_uint, c_longlong, p, p]
+    L.ocrl_slate_soft_z.argtypes = [p, p]
     L.ocrl_gemm.argtypes = [p, p, p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, p, c_int, p, c_int, p, c_int,
                             c_int, p, p]
     L.ocrl_conv2d_fwd.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, p, p]

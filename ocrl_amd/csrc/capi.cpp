@@ -105,6 +105,7 @@ int ocrl_slate_clip_adam(ocrl_slate* h, const float lr[3], float clip, int step,
 int ocrl_slate_grad_norm(ocrl_slate* h, void* stream) { GUARD(h); return h->m->grad_norm(ST(stream)); }
 float* ocrl_slate_metrics(const ocrl_slate* h) { return (h && h->m) ? h->m->metrics() : nullptr; }
 int ocrl_slate_tensor(const ocrl_slate* h, const char* name, float** ptr, long long* count) { GUARD(h); return h->m->tensor(name, ptr, count); }
+int ocrl_slate_soft_z(ocrl_slate* h, void* stream) { GUARD(h); return h->m->soft_z(ST(stream)); }
 int ocrl_slate_dropout_mask(const ocrl_slate* h, unsigned site, long long n, float* out, void* stream) {
     GUARD(h);
     return h->m->dropout_mask(site, n, out, ST(stream));

@@ -422,6 +422,80 @@ __global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ pred, const
     }
 }
 
+// ------------------------------------------------------------------ soft-max heads fused into the vocabulary GEMMs (gemm.hip, epi_mode 1-3)
+// One wave per row, lane = 64-column segment: combines the per-segment (max, sum-exp) pairs the GEMM epilogue left in `stat` into
+// lse[row]; optionally picks the hard Gumbel sample (first maximum over the segment maxima -> tokens[row]) and the cross-entropy term
+// lse - pred[row, tok[row]], summed per block (16 rows, fixed order) into part[block].
+__global__ __launch_bounds__(1024) void softmax_stat_combine_kernel(const float* __restrict__ stat, int nseg, long long R, float* __restrict__ lse,
+                                                                    const float* __restrict__ hstat, const int* __restrict__ hidx,
+                                                                    int* __restrict__ tokens, const float* __restrict__ pred, int ldp,
+                                                                    const int* __restrict__ tok, float* __restrict__ part) {
+    __shared__ float red[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 16 + wave;
+    float loss = 0.f;
+    if (row < R) {
+        float m = -INFINITY, sv = 0.f;
+        if (lane < nseg) { m = stat[((size_t)row * nseg + lane) * 2]; sv = stat[((size_t)row * nseg + lane) * 2 + 1]; }
+        float mx = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float t = m > -INFINITY ? sv * __expf(m - mx) : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        const float l = mx + __logf(t);
+        if (lane == 0) lse[row] = l;
+        if (hstat) {
+            float b = -INFINITY;
+            int bi = 0x7fffffff;
+            if (lane < nseg) { b = hstat[(size_t)row * nseg + lane]; bi = hidx[(size_t)row * nseg + lane]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(b, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+            }
+            if (lane == 0) tokens[row] = bi;
+        }
+        if (part && lane == 0) loss = l - pred[(size_t)row * ldp + tok[row]];
+    }
+    if (part) {
+        if (lane == 0) red[wave] = loss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += red[k];
+            part[blockIdx.x] = a;
+        }
+    }
+}
+// z[row, v] = exp(y[row, v] - lse[row]): the soft-max the fused heads never write, for callers that ask for it (with_rep, tests)
+__global__ __launch_bounds__(256) void exp_rows_kernel(const float* __restrict__ y, const float* __restrict__ lse, float* __restrict__ z, long long n4, int V4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float l = lse[i / V4];
+    const float4 v = *reinterpret_cast<const float4*>(y + i * 4);
+    *reinterpret_cast<float4*>(z + i * 4) = make_float4(__expf(v.x - l), __expf(v.y - l), __expf(v.z - l), __expf(v.w - l));
+}
+// out[row] = sum_c g[row,c] * (act[row,c] - bias[c]),  64 channels, 16 lanes x float4 per row.  With act = relu(z W^T + bias) and g the
+// gradient behind that ReLU this is sum_v z_v (dL/dz_v): the row term of the soft-max backward, without a pass over the vocabulary.
+__global__ __launch_bounds__(256) void rowdot_bias64_kernel(const float* __restrict__ g, const float* __restrict__ act, const float* __restrict__ bias,
+                                                            long long R, float* __restrict__ out) {
+    const int c4 = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float a = 0.f;
+    if (row < R) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + row * 64 + c4 * 4);
+        const float4 av = *reinterpret_cast<const float4*>(act + row * 64 + c4 * 4);
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        a = (gv.x * (av.x - bv.x) + gv.y * (av.y - bv.y)) + (gv.z * (av.z - bv.z) + gv.w * (av.w - bv.w));
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o, 64);
+    if (row < R && c4 == 0) out[row] = a;
+}
+
 // ------------------------------------------------------------------ token embedding (+BOS, +pos, dropout)
 // out[b,t,:] = drop( (t==0 ? bos : dict[tok[b,t-1]]) + pe[t] ),  dropout index over the reference's [B,T+1,d] tensor
 __global__ void embed_fwd_kernel(const int* __restrict__ tokens, const float* __restrict__ dict, const float* __restrict__ bos,
@@ -1093,6 +1167,31 @@ int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, in
     else hipLaunchKernelGGL(ce_kernel<0>, dim3((unsigned)R), dim3(256), 0, st, pred, tokens, ws, V, 1.0f / B, write_grad);
     OCRL_CHECK_LAUNCH("ce");
     return reduce_partials_launch(ws, (int)R, out, 1.0f / B, 0, st);
+}
+// lse [R]; tokens (with hstat / hidx) and the cross-entropy sum (with pred / tok; out[0] = scale * sum, ws >= ceil(R/16) floats) are optional
+int softmax_stat_combine_launch(const float* stat, int nseg, long long R, float* lse, const float* hstat, const int* hidx, int* tokens,
+                                const float* pred, int ldp, const int* tok, float* out, float scale, float* ws, size_t ws_floats, hipStream_t st) {
+    OCRL_REQUIRE(nseg >= 1 && nseg <= 64, "softmax_stat_combine: 1..64 segments (got %d)", nseg);
+    const long long nblk = (R + 15) / 16;
+    OCRL_REQUIRE(!pred || (tok && out && ws && ws_floats >= (size_t)nblk), "softmax_stat_combine: cross-entropy needs tokens, an output and %lld workspace floats", nblk);
+    hipLaunchKernelGGL(softmax_stat_combine_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, stat, nseg, R, lse, hstat, hidx, tokens, pred, ldp, tok,
+                       pred ? ws : nullptr);
+    OCRL_CHECK_LAUNCH("softmax_stat_combine");
+    if (pred) return reduce_partials_launch(ws, (int)nblk, out, scale, 0, st);
+    return 0;
+}
+int exp_rows_launch(const float* y, const float* lse, float* z, long long R, int V, hipStream_t st) {
+    OCRL_REQUIRE(V % 4 == 0, "exp_rows: V %% 4 != 0");
+    const long long n4 = R * (V / 4);
+    hipLaunchKernelGGL(exp_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, lse, z, n4, V / 4);
+    OCRL_CHECK_LAUNCH("exp_rows");
+    return 0;
+}
+int rowdot_bias64_launch(const float* g, const float* act, const float* bias, long long R, float* out, hipStream_t st) {
+    OCRL_REQUIRE(((((uintptr_t)g) | ((uintptr_t)act) | ((uintptr_t)bias)) & 15) == 0, "rowdot: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(rowdot_bias64_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, st, g, act, bias, R, out);
+    OCRL_CHECK_LAUNCH("rowdot_bias64");
+    return 0;
 }
 int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,
                      unsigned long long seed, hipStream_t st) {

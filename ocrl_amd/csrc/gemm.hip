@@ -103,6 +103,52 @@ __device__ inline void store_tile(float* __restrict__ s, const float4 (&r)[TileA
     }
 }
 
+// ---- soft-max operand transforms (GemmArgs::a_mode / b_mode): the stored scores become probabilities / cross-entropy gradients while
+// the tile goes from registers to LDS.  The per-row constants are fetched together with the tile (load_aux) and consumed a whole
+// MFMA phase later (xform_tile), so no load is waited on early.  Padding elements get lse = +inf -> exp(0 - inf) = 0.
+#define TINYF_G 1.17549435e-38f
+template <int BMN, bool KC>
+__device__ inline void load_aux(const float* __restrict__ lse, const int* __restrict__ tok, int rows_valid, int k_valid, int mn0, int k0,
+                                float (&al)[TileA<BMN, KC>::NV], int (&at)[TileA<BMN, KC>::NV]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < TileA<BMN, KC>::NV; ++i) {
+        int trow;
+        bool ok;
+        if (KC) {
+            const int c4 = t % TileA<BMN, KC>::KF4, row = t / TileA<BMN, KC>::KF4 + TileA<BMN, KC>::KRPP * i;
+            ok = row < rows_valid && c4 * 4 < k_valid;
+            trow = mn0 + row;
+        } else {
+            constexpr int F4 = BMN / 4, RPP = 256 / F4;
+            const int c4 = t % F4, r0 = t / F4, kr = r0 + RPP * i;
+            ok = r0 < RPP && kr < BK && kr < k_valid && c4 * 4 < rows_valid;
+            trow = k0 + kr;
+        }
+        al[i] = ok ? lse[trow] : INFINITY;
+        at[i] = (ok && tok) ? tok[trow] : -0x40000000;
+    }
+}
+template <int BMN, bool KC>
+__device__ inline void xform_tile(int mode, float scale, int mn0, int k0, float4 (&r)[TileA<BMN, KC>::NV],
+                                  const float (&al)[TileA<BMN, KC>::NV], const int (&at)[TileA<BMN, KC>::NV]) {
+    const int t = threadIdx.x;
+    const int c4 = KC ? t % TileA<BMN, KC>::KF4 : t % (BMN / 4);
+    const int col0 = (KC ? k0 : mn0) + c4 * 4;          // vocabulary index of .x
+#pragma unroll
+    for (int i = 0; i < TileA<BMN, KC>::NV; ++i) {
+        float4 v = r[i];
+        const float l = al[i];
+        v.x = __expf(v.x - l); v.y = __expf(v.y - l); v.z = __expf(v.z - l); v.w = __expf(v.w - l);
+        if (mode == 3) {
+            const int tk = at[i] - col0;
+            v.x = (v.x - (tk == 0 ? 1.f : 0.f)) * scale; v.y = (v.y - (tk == 1 ? 1.f : 0.f)) * scale;
+            v.z = (v.z - (tk == 2 ? 1.f : 0.f)) * scale; v.w = (v.w - (tk == 3 ? 1.f : 0.f)) * scale;
+        }
+        r[i] = v;
+    }
+}
+
 // fragment for one 32-row MFMA tile, 8-k chunk c: f[j] is the operand of MFMA step j.
 template <int BMN, bool KC>
 __device__ inline void load_frag(const float* __restrict__ s, int row0, int c, float (&f)[4]) {
@@ -118,8 +164,10 @@ __device__ inline void load_frag(const float* __restrict__ s, int row0, int c, f
     }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool SB, bool ADROP>
+// XF: 0 plain operands, 1 A-operand dropout, 2 soft-max operand transforms (a_mode / b_mode);  EPI: GemmArgs::epi_mode (0 = standard epilogue)
+template <int BM, int BN, bool AKC, bool BKC, bool SB, int XF, int EPI>
 __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 * 64) ? 4 : 1)) void gemm_kernel(GemmArgs p) {
+    constexpr bool ADROP = XF == 1;
     constexpr int TM = BM / 64, TN = BN / 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int AE = TileA<BM, AKC>::ELEMS, BE = TileA<BN, BKC>::ELEMS;
@@ -176,15 +224,32 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
         }
     };
     float4 ra[TileA<BM, AKC>::NV], rb[TileA<BN, BKC>::NV];
+    // soft-max operand transforms: per-row constants of the tile held in ra / rb
+    float ala[XF == 2 ? TileA<BM, AKC>::NV : 1], alb[XF == 2 ? TileA<BN, BKC>::NV : 1];
+    int ata[XF == 2 ? TileA<BM, AKC>::NV : 1], atb[XF == 2 ? TileA<BN, BKC>::NV : 1];
+    auto aux_load = [&](int k0) {
+        if constexpr (XF == 2) {
+            if (p.a_mode) load_aux<BM, AKC>(p.x_lse, p.a_mode == 3 ? p.x_tok : nullptr, mval, p.K - k0, m0, k0, ala, ata);
+            if (p.b_mode) load_aux<BN, BKC>(p.x_lse, nullptr, nval, p.K - k0, n0, k0, alb, atb);
+        }
+    };
+    auto aux_apply = [&](int k0) {
+        if constexpr (XF == 2) {
+            if (p.a_mode) xform_tile<BM, AKC>(p.a_mode, p.x_scale, m0, k0, ra, ala, ata);
+            if (p.b_mode) xform_tile<BN, BKC>(p.b_mode, 1.f, n0, k0, rb, alb, atb);
+        }
+    };
     if (SB) {
         // single LDS buffer (half the LDS -> twice the resident workgroups): next tile's global loads fly during compute
         if (kt0 < kt1) {
             const int k0 = kt0 * BK;
             load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
             load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
+            aux_load(k0);
         }
         for (int kt = kt0; kt < kt1; ++kt) {
             __syncthreads();
+            aux_apply(kt * BK);
             store_tile<BM, AKC>(As0, ra);
             store_tile<BN, BKC>(Bs0, rb);
             __syncthreads();
@@ -192,6 +257,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                 const int k0 = (kt + 1) * BK;
                 load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
                 load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
+                aux_load(k0);
             }
             bias_acc(As0);
 #pragma unroll
@@ -215,6 +281,8 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
         const int k0 = kt0 * BK;
         load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
         load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
+        aux_load(k0);
+        aux_apply(k0);
         store_tile<BM, AKC>(As0, ra);
         store_tile<BN, BKC>(Bs0, rb);
     }
@@ -225,6 +293,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
             const int k0 = (kt + 1) * BK;
             load_tile<BM, AKC, ADROP>(AKC ? Ag + k0 : Ag + (size_t)k0 * p.lda, p.lda, mval, p.K - k0, ra, adr, m0, k0);
             load_tile<BN, BKC, false>(BKC ? Bg + k0 : Bg + (size_t)k0 * p.ldb, p.ldb, nval, p.K - k0, rb, adr, n0, k0);
+            aux_load(k0);
         }
         const float* as = As0 + cur * AE;
         const float* bs = Bs0 + cur * BE;
@@ -245,6 +314,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < kt1) {
+            aux_apply((kt + 1) * BK);
             store_tile<BM, AKC>(As0 + (cur ^ 1) * AE, ra);
             store_tile<BN, BKC>(Bs0 + (cur ^ 1) * BE, rb);
         }
@@ -261,6 +331,112 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
     const float* Mk = p.mask ? p.mask + (size_t)batch * p.sMask : nullptr;
     const uint32_t thr = drop_thresh(p.drop_p);
     const float dscale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    if constexpr (EPI != 0) {
+        // ---- soft-max head epilogues (GemmArgs::epi_mode).  Same patch walk as the fast path below: in a patch pass the 8 lanes with
+        // equal (lane >> 3) hold the 32 columns of one row, so a row reduction is three xor-shuffles; the TN patches of a wave row are
+        // merged online, giving one (max, sum-exp) pair per row and 64-column segment.  All reductions have a fixed order.
+        __syncthreads();
+        float* patch = smem + wave * (32 * 36);
+        const int rr0 = lane >> 3, c4 = lane & 7;
+        const int nseg = 2 * nbn, seg = 2 * bn + (wave & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float sm[4], ss[4], hb[4], rl[4], rv[4];
+            int hi[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                sm[ps] = -INFINITY; ss[ps] = 0.f; hb[ps] = -INFINITY; hi[ps] = 0; rl[ps] = 0.f; rv[ps] = 0.f;
+                const int row = m0 + wm0 + i * 32 + ps * 8 + rr0;
+                if (EPI == 3 && row < p.M) { rl[ps] = p.e_lse[row]; rv[ps] = p.e_rowvec[row]; }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = acc[i][j][r] * p.alpha;
+                __builtin_amdgcn_wave_barrier();
+                const int col = n0 + wn0 + j * 32 + c4 * 4;
+                const bool cok = col < p.N;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias && cok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int rr = ps * 8 + rr0;
+                    const int row = m0 + wm0 + i * 32 + rr;
+                    const bool ok = cok && row < p.M;
+                    float4 v = *reinterpret_cast<const float4*>(patch + rr * 36 + c4 * 4);
+                    if (EPI == 3) {
+                        if (ok) {
+                            const float4 y = *reinterpret_cast<const float4*>(p.mask + (size_t)row * p.ldmask + col);
+                            const float l = rl[ps], dv = rv[ps];
+                            v.x = __expf(y.x - l) * (v.x - dv) * p.e_scale; v.y = __expf(y.y - l) * (v.y - dv) * p.e_scale;
+                            v.z = __expf(y.z - l) * (v.z - dv) * p.e_scale; v.w = __expf(y.w - l) * (v.w - dv) * p.e_scale;
+                            *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + col) = v;
+                        }
+                        continue;
+                    }
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (EPI == 2) {
+                        float4 ea = make_float4(1.f, 1.f, 1.f, 1.f), eb = ea;
+                        if (ok) {
+                            const uint64_t idx = (uint64_t)row * (uint64_t)p.N + col;
+                            if (p.e1) {
+                                ea = *reinterpret_cast<const float4*>(p.e1 + idx);
+                                eb = *reinterpret_cast<const float4*>(p.e2 + idx);
+                            } else {
+                                const uint2 b0 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx), b1 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx + 1);
+                                const uint2 b2 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx + 2), b3 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx + 3);
+                                ea = make_float4(-__logf(u01_24(b0.x)), -__logf(u01_24(b1.x)), -__logf(u01_24(b2.x)), -__logf(u01_24(b3.x)));
+                                eb = make_float4(-__logf(u01_24(b0.y)), -__logf(u01_24(b1.y)), -__logf(u01_24(b2.y)), -__logf(u01_24(b3.y)));
+                            }
+                        }
+                        // hard sample: (l + g2) / tau, first maximum
+                        const float h0 = (v.x - __logf(eb.x + TINYF_G)) * p.e_scale, h1 = (v.y - __logf(eb.y + TINYF_G)) * p.e_scale;
+                        const float h2 = (v.z - __logf(eb.z + TINYF_G)) * p.e_scale, h3 = (v.w - __logf(eb.w + TINYF_G)) * p.e_scale;
+                        float b = h0; int bi = col;
+                        if (h1 > b) { b = h1; bi = col + 1; }
+                        if (h2 > b) { b = h2; bi = col + 2; }
+                        if (h3 > b) { b = h3; bi = col + 3; }
+                        if (!cok) b = -INFINITY;
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) {
+                            const float ob = __shfl_xor(b, o, 64);
+                            const int oi = __shfl_xor(bi, o, 64);
+                            if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
+                        }
+                        if (b > hb[ps]) { hb[ps] = b; hi[ps] = bi; }          // later patches hold higher columns: only a strictly larger value wins
+                        // soft sample scores
+                        v.x = (v.x - __logf(ea.x + TINYF_G)) * p.e_scale; v.y = (v.y - __logf(ea.y + TINYF_G)) * p.e_scale;
+                        v.z = (v.z - __logf(ea.z + TINYF_G)) * p.e_scale; v.w = (v.w - __logf(ea.w + TINYF_G)) * p.e_scale;
+                    }
+                    float lm = cok ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : -INFINITY;
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) lm = fmaxf(lm, __shfl_xor(lm, o, 64));
+                    float le = cok ? (__expf(v.x - lm) + __expf(v.y - lm)) + (__expf(v.z - lm) + __expf(v.w - lm)) : 0.f;
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) le += __shfl_xor(le, o, 64);
+                    if (lm > -INFINITY) {
+                        const float mn = fmaxf(sm[ps], lm);
+                        ss[ps] = ss[ps] * __expf(sm[ps] - mn) + le * __expf(lm - mn);
+                        sm[ps] = mn;
+                    }
+                    if (ok) *reinterpret_cast<float4*>(C + (size_t)row * p.ldc + col) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (EPI != 3 && c4 == 0) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int row = m0 + wm0 + i * 32 + ps * 8 + rr0;
+                    if (row >= p.M) continue;
+                    const size_t si = (size_t)row * nseg + seg;
+                    p.stat[si * 2] = sm[ps];
+                    p.stat[si * 2 + 1] = ss[ps];
+                    if (EPI == 2) { p.hstat[si] = hb[ps]; p.hidx[si] = hi[ps]; }
+                }
+            }
+        }
+        return;
+    }
     // Fast path: every 32x32 accumulator tile goes through a wave-private LDS patch and leaves as float4 rows — 4x fewer store
     // (and mask / residual load) instructions, full 128-byte lines, and one dropout draw per 4 outputs instead of one per output.
     const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!R || ((p.ldr & 3) == 0 && (((uintptr_t)R) & 15) == 0)) &&
@@ -387,26 +563,32 @@ static int sb_mode() {
     return v;
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool SB, bool ADROP>
+template <int BM, int BN, bool AKC, bool BKC, bool SB, int XF, int EPI = 0>
 static int launch_cfg3(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = ((SB ? 1 : 2) * TileA<BM, AKC>::ELEMS + (SB ? 1 : 2) * TileA<BN, BKC>::ELEMS) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, AKC, BKC, SB, ADROP>,
+        OCRL_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, AKC, BKC, SB, XF, EPI>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     dim3 grid(cdiv(a.M, BM) * cdiv(a.N, BN), a.batch * a.splitk);
     const int pi = prof_begin(PROF_GEMM, st);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, SB, ADROP>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, SB, XF, EPI>), grid, dim3(256), smem, st, a);
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("gemm_kernel");
     return 0;
 }
 template <int BM, int BN, bool AKC, bool BKC, bool SB>
 static int launch_cfg2(const GemmArgs& a, hipStream_t st) {
-    if (a.adrop_p > 0.f) return launch_cfg3<BM, BN, AKC, BKC, SB, true>(a, st);
-    return launch_cfg3<BM, BN, AKC, BKC, SB, false>(a, st);
+    if (a.a_mode || a.b_mode) {
+        if constexpr (AKC || !BKC)
+            return launch_cfg3<BM, BN, AKC, BKC, SB, 2>(a, st);
+        else
+            OCRL_REQUIRE(false, "gemm: operand transform not built for tile %dx%d akc=%d bkc=%d", BM, BN, (int)AKC, (int)BKC);
+    }
+    if (a.adrop_p > 0.f) return launch_cfg3<BM, BN, AKC, BKC, SB, 1>(a, st);
+    return launch_cfg3<BM, BN, AKC, BKC, SB, 0>(a, st);
 }
 template <int BM, int BN, bool AKC, bool BKC>
 static int launch_cfg(const GemmArgs& a, hipStream_t st) {
@@ -471,6 +653,26 @@ int gemm_launch(const GemmArgs& a_in, hipStream_t st) {
     if (a.splitk > 1) OCRL_REQUIRE(a.sCsplit >= (long long)(a.M - 1) * a.ldc + a.N, "gemm: split-k slab stride too small");
     if (a.adrop_p > 0.f) OCRL_REQUIRE(a.adrop_ld > 0 && a.adrop_ld % 4 == 0 && a.batch == 1, "gemm: A-dropout needs adrop_ld %% 4 == 0 and no batching");
     if (a.bias_out) OCRL_REQUIRE(!a.akc && (a.splitk == 1 || a.sBias >= a.M), "gemm: fused bias gradient needs the dW form");
+    OCRL_REQUIRE(!(a.a_mode || a.b_mode) || (a.batch == 1 && a.adrop_p == 0.f && a.x_lse && (a.a_mode != 3 || a.x_tok) &&
+                 (a.a_mode == 0 || a.a_mode == 2 || a.a_mode == 3) && (a.b_mode == 0 || a.b_mode == 2)), "gemm: bad operand transform arguments");
+    if (a.epi_mode) {
+        OCRL_REQUIRE(a.akc && a.batch == 1 && a.splitk == 1 && !a.a_mode && !a.b_mode && a.adrop_p == 0.f && a.relu == 0 && a.drop_p == 0.f && !a.resid,
+                     "gemm: soft-max epilogue needs a plain k-contiguous A, no split-k / batches / activation");
+        OCRL_REQUIRE((a.N & 3) == 0 && (a.ldc & 3) == 0 && (((uintptr_t)a.C) & 15) == 0 && (!a.bias || (((uintptr_t)a.bias) & 15) == 0),
+                     "gemm: soft-max epilogue needs N, ldc multiples of 4 and 16-byte aligned C / bias");
+        if (a.epi_mode == 1 || a.epi_mode == 2) {
+            OCRL_REQUIRE(a.bkc && a.stat && !a.mask && gemm_stat_segments(a.N) <= 64, "gemm: soft-max statistics need a k-contiguous B, a stat buffer and N <= 4096");
+            if (a.epi_mode == 2) {
+                OCRL_REQUIRE(a.hstat && a.hidx && (a.e1 == nullptr) == (a.e2 == nullptr) && a.ldc == a.N, "gemm: Gumbel head arguments");
+                OCRL_REQUIRE(!a.e1 || ((((uintptr_t)a.e1) | ((uintptr_t)a.e2)) & 15) == 0, "gemm: Gumbel noise must be 16-byte aligned");
+                return launch_cfg3<128, 128, true, true, true, 0, 2>(a, st);
+            }
+            return launch_cfg3<128, 128, true, true, true, 0, 1>(a, st);
+        }
+        OCRL_REQUIRE(a.epi_mode == 3 && !a.bkc && a.mask && a.e_lse && a.e_rowvec && !a.bias && (a.ldmask & 3) == 0 && (((uintptr_t)a.mask) & 15) == 0,
+                     "gemm: soft-max backward epilogue arguments");
+        return launch_cfg3<128, 128, true, false, true, 0, 3>(a, st);
+    }
     if (a.akc && a.bkc) return launch_tr<true, true>(a, st);
     if (a.akc && !a.bkc) return launch_tr<true, false>(a, st);
     if (!a.akc && !a.bkc) return launch_tr<false, false>(a, st);

@@ -37,7 +37,25 @@ struct GemmArgs {
     float adrop_p = 0.f; unsigned adrop_site = 0; int adrop_ld = 0;
     // fused bias gradient for the dW form (akc == 0): bias_out[m] = sum_k A(m,k)  (partials per split at stride sBias)
     float* bias_out = nullptr; long long sBias = 0;
+    // ---- soft-max heads fused into the product (the [rows, vocabulary] tensor is written once and never re-read by an elementwise pass)
+    // operand transforms, applied while an operand tile is staged; `row` is the token row (the m index of a k-contiguous A, the k index
+    // of an m/n-contiguous A or B), `col` the vocabulary index:
+    //   2: exp(x - x_lse[row])                                    (soft-max probabilities rebuilt from the stored scores)
+    //   3: (exp(x - x_lse[row]) - [col == x_tok[row]]) * x_scale  (cross-entropy gradient rebuilt from the stored logits; A only)
+    int a_mode = 0, b_mode = 0;
+    const float* x_lse = nullptr; const int* x_tok = nullptr; float x_scale = 1.f;
+    // epilogue modes (128x128 tiles, k-contiguous A, N % 4 == 0, no split-k / batches):
+    //   1: C = alpha*acc (+bias) and per (row, 64-column segment) soft-max statistics  stat[(row*nseg + seg)*2 + {0,1}] = (max, sum exp(v - max))
+    //   2: Gumbel head: l = acc + bias;  C = (l + g1) * e_scale  with statistics as in 1;  the hard sample's segment maximum of
+    //      (l + g2) * e_scale and its column go to hstat / hidx.  g = -log(E + tiny), E from e1 / e2 (injected Exp(1) noise, [M,N]) or
+    //      from the counter RNG (e_seed, the same draws as gumbel_softmax_kernel)
+    //   3: soft-max backward: C = exp(mask - e_lse[row]) * (acc - e_rowvec[row]) * e_scale   (mask = the stored scores; C may alias mask)
+    int epi_mode = 0;
+    float* stat = nullptr; float* hstat = nullptr; int* hidx = nullptr;
+    const float* e1 = nullptr; const float* e2 = nullptr; unsigned long long e_seed = 0;
+    const float* e_lse = nullptr; const float* e_rowvec = nullptr; float e_scale = 1.f;
 };
+inline int gemm_stat_segments(int N) { return 2 * ((N + 127) / 128); }
 int gemm_launch(const GemmArgs& a, hipStream_t st);
 int splitk_reduce_launch(const float* part, float* out, long long n, int splits, long long stride,
                          int accumulate, hipStream_t st);
@@ -84,6 +102,10 @@ int mse_launch(const float* obs, const float* recon, float* drecon, float* out, 
 int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, float* z, int* tokens, long long R, int V, float tau,
                           unsigned long long seed, hipStream_t st, float* zst = nullptr);
 int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st);
+int softmax_stat_combine_launch(const float* stat, int nseg, long long R, float* lse, const float* hstat, const int* hidx, int* tokens,
+                                const float* pred, int ldp, const int* tok, float* out, float scale, float* ws, size_t ws_floats, hipStream_t st);
+int exp_rows_launch(const float* y, const float* lse, float* z, long long R, int V, hipStream_t st);
+int rowdot_bias64_launch(const float* g, const float* act, const float* bias, long long R, float* out, hipStream_t st);
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st);
 int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,
                      unsigned long long seed, hipStream_t st);

@@ -188,6 +188,13 @@ void SlateModel::layout_workspace(bool commit) {
     z_ = carve("z", BT * V);
     zdec_ = cfg.hard ? carve("z_st", BT * V) : z_;
     tokens_ = reinterpret_cast<int*>(carve("tokens", BT));
+    // soft-max heads fused into the vocabulary GEMMs: per-row / per-segment statistics (gemm.hip epi_mode 1-3)
+    {
+        const size_t nseg = (size_t)gemm_stat_segments(V);
+        zstat_ = carve(nullptr, BT * nseg * 2); zhstat_ = carve(nullptr, BT * nseg); zhidx_ = reinterpret_cast<int*>(carve(nullptr, BT * nseg));
+        zlse_ = carve("z_lse", BT); zdot_ = carve(nullptr, BT);
+        cestat_ = carve(nullptr, BT * nseg * 2); celse_ = carve("ce_lse", BT); cepart_ = carve(nullptr, BT / 16 + 16);
+    }
     // post-activation outputs of the dVAE decoder blocks (named: the parity tests read their ReLU masks)
     dd0_ = carve("dvae_dec0", BT * 64); dd1_ = carve("dvae_dec1", BT * 64); dd2_ = carve("dvae_dec2", BT * 64); dd3_ = carve("dvae_dec3", BT * 64);
     dd4_ = carve("dvae_dec4", BT * 256); ps1_ = carve(nullptr, BT * 256);
@@ -294,6 +301,11 @@ int SlateModel::tensor(const char* name, float** ptr, long long* count) const {
     return 0;
 }
 
+int SlateModel::soft_z(hipStream_t st) {
+    if (!fused_heads() || cfg.use_bcdec) return 0;          // z_ is written by the forward itself
+    OCRL_REQUIRE(have_scores_, "soft_z: no forward since the last backward (the scores have been overwritten by their gradient)");
+    return exp_rows_launch(zraw_, zlse_, z_, (long long)last_.B * T, V, st);
+}
 int SlateModel::dropout_mask(unsigned site, long long n, float* out, hipStream_t st) const {
     return dropout_mask_launch(out, n, pdrop_, last_.seed, site, st);
 }
@@ -308,8 +320,9 @@ int SlateModel::lin_fwd(const float* x, int ldx, const float* W, const float* b,
 }
 // dx[M,K_in] = (drop(dy)[M,N_out] W[N_out,K_in]) * (mask > 0) + resid
 int SlateModel::lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx, int ldx, long long M, int N_out, int K_in,
-                          const float* mask, int ldmask, const float* resid, int ldr, hipStream_t st, Drop dr) {
+                          const float* mask, int ldmask, const float* resid, int ldr, hipStream_t st, Drop dr, Xf xf) {
     GemmArgs a;
+    a.a_mode = xf.a_mode; a.b_mode = xf.b_mode; a.x_lse = xf.lse; a.x_tok = xf.tok; a.x_scale = xf.scale;
     a.A = dy; a.B = W; a.C = dx; a.M = (int)M; a.N = K_in; a.K = N_out; a.lda = ld_dy; a.ldb = K_in; a.ldc = ldx; a.akc = 1; a.bkc = 0;
     a.mask = mask; a.ldmask = ldmask; a.resid = resid; a.ldr = ldr;
     if (dr.p > 0.f) { a.adrop_p = dr.p; a.adrop_site = dr.site; a.adrop_ld = N_out; a.drop_seed = last_.seed; }
@@ -317,8 +330,9 @@ int SlateModel::lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx,
 }
 // dW[N_out,K_in] = alpha * drop(dy)^T x (split over the M rows);  db[N_out] = column sums of drop(dy), fused into the GEMM
 int SlateModel::lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in,
-                          float alpha, hipStream_t st, Drop dr) {
+                          float alpha, hipStream_t st, Drop dr, Xf xf) {
     GemmArgs a;
+    a.a_mode = xf.a_mode; a.b_mode = xf.b_mode; a.x_lse = xf.lse; a.x_tok = xf.tok; a.x_scale = xf.scale;
     a.A = dy; a.B = x; a.C = dW; a.M = N_out; a.N = K_in; a.K = (int)M; a.lda = ld_dy; a.ldb = ldx; a.ldc = K_in; a.akc = 0; a.bkc = 0;
     a.alpha = alpha;
     if (dr.p > 0.f) { a.adrop_p = dr.p; a.adrop_site = dr.site; a.adrop_ld = N_out; a.drop_seed = last_.seed; }
@@ -418,19 +432,41 @@ int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
     RC(lin_fwd(patches_, 16 * ch, P("_dvae._encoder.0.m.weight"), P("_dvae._encoder.0.m.bias"), de_[0], 64, BT, 64, 16 * ch, 1, nullptr, 0, 0.f, 0, st));
     for (int i = 1; i < 7; ++i)
         RC(lin_fwd(de_[i - 1], 64, P(fmt("_dvae._encoder.%d.m.weight", i)), P(fmt("_dvae._encoder.%d.m.bias", i)), de_[i], 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
+    if (fused_heads()) {
+        // 64 -> vocabulary head with both Gumbel samples in its epilogue (ocrs/slate/slate_module.py:125-127, ocrs/common/utils.py:72-85):
+        // zraw_ <- (logits + g1) / tau, the soft sample's scores.  z = softmax(zraw_) is never written: the decoder product and the
+        // backward rebuild it from zraw_ and z_lse while staging their operand tiles.  (The reference adds the noise to
+        // log_softmax(logits); the row shift cancels in the soft-max and in the argmax.)
+        GemmArgs a;
+        a.A = de_[6]; a.B = P("_dvae._encoder.7.weight"); a.C = zraw_; a.M = (int)BT; a.N = V; a.K = 64; a.lda = 64; a.ldb = 64; a.ldc = V;
+        a.bias = P("_dvae._encoder.7.bias");
+        a.epi_mode = 2; a.stat = zstat_; a.hstat = zhstat_; a.hidx = zhidx_; a.e1 = in.noise_z; a.e2 = in.noise_zh; a.e_seed = in.seed;
+        a.e_scale = 1.0f / in.tau;
+        RC(gemm_launch(a, st));
+        RC(softmax_stat_combine_launch(zstat_, gemm_stat_segments(V), BT, zlse_, zhstat_, zhidx_, tokens_, nullptr, 0, nullptr, nullptr, 0.f, nullptr, 0, st));
+        have_scores_ = true;
+    } else {
     RC(lin_fwd(de_[6], 64, P("_dvae._encoder.7.weight"), P("_dvae._encoder.7.bias"), zraw_, V, BT, V, 64, 0, nullptr, 0, 0.f, 0, st));
     RC(gumbel_softmax_launch(zraw_, in.noise_z, in.noise_zh, z_, tokens_, BT, V, in.tau, in.seed, st, cfg.hard ? zdec_ : nullptr));
+    }
     RC(dvae_decode(B, drecon_, st));
     return 0;
 }
 
 // dVAE decoder on z_ -> recon_ (ocrs/common/models.py:24-37,44-45) and the reconstruction loss into metrics[0]
 int SlateModel::dvae_decode(int B, float* drecon, hipStream_t st, const float* zin) {
-    if (!zin) zin = zdec_;
     const long long BT = (long long)B * T, BN = (long long)B * N;
     const int ch = cfg.obs_channels;
     // decoder
+    if (!zin && fused_heads()) {
+        GemmArgs a;        // A = softmax(zraw_) rebuilt on the fly
+        a.A = zraw_; a.B = P("_dvae._decoder.0.m.weight"); a.C = dd0_; a.M = (int)BT; a.N = 64; a.K = V; a.lda = V; a.ldb = V; a.ldc = 64;
+        a.bias = P("_dvae._decoder.0.m.bias"); a.relu = 1; a.a_mode = 2; a.x_lse = zlse_;
+        RC(gemm_launch(a, st));
+    } else {
+    if (!zin) zin = zdec_;
     RC(lin_fwd(zin, V, P("_dvae._decoder.0.m.weight"), P("_dvae._decoder.0.m.bias"), dd0_, 64, BT, 64, V, 1, nullptr, 0, 0.f, 0, st));
+    }
     RC(conv_layer_fwd(dd0_, dw_fwd_[0], P("_dvae._decoder.1.m.bias"), dd1_, B, E, E, 3, 64, 1, nullptr, nullptr, st));
     RC(lin_fwd(dd1_, 64, P("_dvae._decoder.2.m.weight"), P("_dvae._decoder.2.m.bias"), dd2_, 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
     RC(lin_fwd(dd2_, 64, P("_dvae._decoder.3.m.weight"), P("_dvae._decoder.3.m.bias"), dd3_, 64, BT, 64, 64, 1, nullptr, 0, 0.f, 0, st));
@@ -484,8 +520,16 @@ int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
         xin = k.x3;
     }
     RC(layernorm_fwd_launch(xin, P("_tfdec.layer_norm.weight"), P("_tfdec.layer_norm.bias"), lnf_, lnf_mean_, lnf_rstd_, BT, d, st));
-    RC(lin_fwd(lnf_, d, P("_out.weight"), nullptr, pred_, V, BT, V, d, 0, nullptr, 0, 0.f, 0, st));
-    if (with_ce) RC(ce_launch(pred_, tokens_, metrics_ + 1, BT, V, B, 1, scratch_, scratch_floats_, st));   // pred_ <- d loss / d pred
+    if (with_ce) {
+        // vocabulary head with the cross-entropy statistics in its epilogue (ocrs/slate/slate_module.py:150-156): pred_ keeps the
+        // logits; the gradient (softmax - onehot) / B is rebuilt from pred_ and ce_lse while the backward products stage it
+        GemmArgs a;
+        a.A = lnf_; a.B = P("_out.weight"); a.C = pred_; a.M = (int)BT; a.N = V; a.K = d; a.lda = d; a.ldb = d; a.ldc = V;
+        a.epi_mode = 1; a.stat = cestat_;
+        RC(gemm_launch(a, st));
+        RC(softmax_stat_combine_launch(cestat_, gemm_stat_segments(V), BT, celse_, nullptr, nullptr, nullptr, pred_, V, tokens_, metrics_ + 1, 1.0f / B,
+                                       cepart_, (size_t)(BT / 16 + 16), st));
+    } else RC(lin_fwd(lnf_, d, P("_out.weight"), nullptr, pred_, V, BT, V, d, 0, nullptr, 0, 0.f, 0, st));
     return 0;
 }
 
@@ -597,9 +641,10 @@ int SlateModel::bwd_decoder(hipStream_t st) {
     const long long BT = (long long)B * T, BK = (long long)B * K;
     const float p = pdrop_;
     const float scale = 1.0f / sqrtf((float)DH);
-    // output head: pred_ already holds d loss / d pred
-    RC(lin_bwd_w(pred_, V, lnf_, d, G("_out.weight"), nullptr, BT, V, d, 1.f, st));
-    RC(lin_bwd_x(pred_, V, P("_out.weight"), gt1_, d, BT, V, d, nullptr, 0, nullptr, 0, st));
+    // output head: d loss / d pred = (softmax(pred_) - onehot(tokens)) / B, rebuilt from the logits as both products stage their A tiles
+    Xf ce; ce.a_mode = 3; ce.lse = celse_; ce.tok = tokens_; ce.scale = 1.0f / last_.B;
+    RC(lin_bwd_w(pred_, V, lnf_, d, G("_out.weight"), nullptr, BT, V, d, 1.f, st, Drop(), ce));
+    RC(lin_bwd_x(pred_, V, P("_out.weight"), gt1_, d, BT, V, d, nullptr, 0, nullptr, 0, st, Drop(), ce));
     const float* xlast = blk_[NB - 1].x3;
     RC(layernorm_bwd_launch(gt1_, xlast, lnf_mean_, lnf_rstd_, P("_tfdec.layer_norm.weight"), gx_, G("_tfdec.layer_norm.weight"), BT, d, 0, 0,
                             scratch_, scratch_floats_, st));
@@ -743,7 +788,9 @@ int SlateModel::bwd_dvae(hipStream_t st) {
             RC(splitk_reduce_launch(scratch_, w4, 256, (int)splits, 256, 0, st));
         } else RC(gemm_launch(a, st));
         RC(copy_launch(w4, G("_dvae._decoder.11.weight"), ch * 64, st));
-        RC(colsum_launch(drecon_, 4, G("_dvae._decoder.11.bias"), BN, ch, 0, 1.f, scratch_, scratch_floats_ - 1024, st));
+        // bias gradient: the padded rows are summed as float4 (the 3-wide scalar form ran one 64-lane column group at 0.05 TB/s)
+        RC(colsum_launch(drecon_, 4, w4 + 256, BN, 4, 0, 1.f, scratch_, scratch_floats_ - 1024, st));
+        RC(copy_launch(w4 + 256, G("_dvae._decoder.11.bias"), ch, st));
     }
     RC(lin_bwd_x(drecon_, 4, w11p_, gdA_, 64, BN, 4, 64, nullptr, 0, nullptr, 0, st));                            // gdA = d ps2
     RC(pixel_shuffle_launch(gdA_, gdB_, B, 2 * E, 2 * E, 64, 0, dd9_, st));                                        // gdB = d dd9 (pre-relu) [4BT,256]
@@ -764,11 +811,24 @@ int SlateModel::bwd_dvae(hipStream_t st) {
     RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.2.m.weight"), gdB_, 64, BT, 64, 64, dd1_, 64, nullptr, 0, st));       // gdB = d dd1 (pre-relu)
     RC(conv_layer_wgrad(dd0_, gdB_, G("_dvae._decoder.1.m.weight"), G("_dvae._decoder.1.m.bias"), B, E, E, 3, 64, 64, st));
     RC(conv_layer_fwd(gdB_, dw_bwd_[0], nullptr, gdA_, B, E, E, 3, 64, 0, nullptr, dd0_, st));                     // gdA = d dd0 (pre-relu)
+    float* dz = zraw_;      // the logits / scores are not needed any more: d raw = d logp is built in their place
+    have_scores_ = false;
+    if (fused_heads()) {
+        Xf zx; zx.b_mode = 2; zx.lse = zlse_;
+        RC(lin_bwd_w(gdA_, 64, zraw_, V, G("_dvae._decoder.0.m.weight"), G("_dvae._decoder.0.m.bias"), BT, 64, V, 1.f, st, Drop(), zx));
+        // Gumbel soft-max backward in the epilogue of the dz product: d = z (dz - sum_v z_v dz_v) / tau with
+        // sum_v z_v dz_v = sum_c g_c (z W^T)_c = sum_c g_c (dd0 - bias)_c  (g = gdA_ is zero where the ReLU of dd0 is closed)
+        RC(rowdot_bias64_launch(gdA_, dd0_, P("_dvae._decoder.0.m.bias"), BT, zdot_, st));
+        GemmArgs a;
+        a.A = gdA_; a.B = P("_dvae._decoder.0.m.weight"); a.C = dz; a.M = (int)BT; a.N = V; a.K = 64; a.lda = 64; a.ldb = V; a.ldc = V; a.bkc = 0;
+        a.epi_mode = 3; a.mask = zraw_; a.ldmask = V; a.e_lse = zlse_; a.e_rowvec = zdot_; a.e_scale = 1.0f / last_.tau;
+        RC(gemm_launch(a, st));
+    } else {
     RC(lin_bwd_w(gdA_, 64, zdec_, V, G("_dvae._decoder.0.m.weight"), G("_dvae._decoder.0.m.bias"), BT, 64, V, 1.f, st));
-    float* dz = zraw_;      // the logits are not needed any more: d raw = d logp is built in their place
     RC(lin_bwd_x(gdA_, 64, P("_dvae._decoder.0.m.weight"), dz, V, BT, 64, V, nullptr, 0, nullptr, 0, st));
     // ---- Gumbel softmax + log_softmax backward (row sums of the soft-max gradient vanish, so d raw = d logp)
     RC(softmax_bwd_rows_launch(z_, dz, BT, V, 1.0f / last_.tau, st));
+    }
     // ---- encoder
     RC(lin_bwd_w(dz, V, de_[6], 64, G("_dvae._encoder.7.weight"), G("_dvae._encoder.7.bias"), BT, V, 64, 1.f, st));
     RC(lin_bwd_x(dz, V, P("_dvae._encoder.7.weight"), gdA_, 64, BT, V, 64, de_[6], 64, nullptr, 0, st));

@@ -39,6 +39,8 @@ struct StepInputs {
 
 // dropout-backward mask applied to dy while the GEMM stages it
 struct Drop { float p = 0.f; unsigned site = 0; };
+// soft-max operand transform of a product (GemmArgs::a_mode / b_mode): the operand is rebuilt from stored scores + per-row log-sum-exp
+struct Xf { int a_mode = 0, b_mode = 0; const float* lse = nullptr; const int* tok = nullptr; float scale = 1.f; };
 
 class SlateModel {
 public:
@@ -60,6 +62,9 @@ public:
     float* metrics() const { return metrics_; }                 // device float[8]: dvae_mse, ce, loss, grad absmax
     int tensor(const char* name, float** ptr, long long* count) const;
     int dropout_mask(unsigned site, long long n, float* out, hipStream_t st) const;
+    // writes the soft sample z = softmax(scores) of the last forward into the named tensor "z" (the fused heads keep only the scores;
+    // valid between forward and backward -- the backward builds d logits in place of the scores)
+    int soft_z(hipStream_t st);
     const SlateConfig cfg;
 
 private:
@@ -70,9 +75,11 @@ private:
     int lin_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, long long M, int N, int K, int relu,
                 const float* resid, int ldr, float drop_p, unsigned site, hipStream_t st);
     int lin_bwd_x(const float* dy, int ld_dy, const float* W, float* dx, int ldx, long long M, int N_out, int K_in, const float* mask,
-                  int ldmask, const float* resid, int ldr, hipStream_t st, Drop dr = Drop());
+                  int ldmask, const float* resid, int ldr, hipStream_t st, Drop dr = Drop(), Xf xf = Xf());
     int lin_bwd_w(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in,
-                  float alpha, hipStream_t st, Drop dr = Drop());
+                  float alpha, hipStream_t st, Drop dr = Drop(), Xf xf = Xf());
+    // the Gumbel / cross-entropy soft-max heads live in the vocabulary GEMMs (soft samples; the straight-through `hard` form keeps z)
+    bool fused_heads() const { return !cfg.hard; }
     int conv_layer_fwd(const float* x, const float* pack, const float* bias, float* y, int Bn, int Hh, int Ww, int KS, int CIN, int relu,
                        const float* posmap, const float* mask, hipStream_t st);
     int conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN, int cin_real,
@@ -106,6 +113,7 @@ private:
     StepInputs last_;
     float pdrop_ = 0.f;
     bool have_fwd_ = false;
+    bool have_scores_ = false;        // zraw_ holds the Gumbel scores of last_ (not yet overwritten by their gradient)
 
     // ---- workspace tensors
     float *scratch_ = nullptr;            // transient: split-k slabs, column-sum partials, wgrad slabs
@@ -116,6 +124,8 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     int fork_side(hipStream_t st);
     int join_side(hipStream_t st);
+    float *zstat_ = nullptr, *zhstat_ = nullptr, *zlse_ = nullptr, *zdot_ = nullptr, *cestat_ = nullptr, *celse_ = nullptr, *cepart_ = nullptr;
+    int* zhidx_ = nullptr;
     float *obs8_, *patches_, *de_[7], *zraw_, *z_, *zdec_;      // zdec_: what the dVAE decoder consumes (z_ or its straight-through form)
     int* tokens_;
     float *dd0_, *dd1_, *dd2_, *dd3_, *dd4_, *ps1_, *dd6_, *dd7_, *dd8_, *dd9_, *ps2_, *recon_, *drecon_;

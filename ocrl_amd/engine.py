@@ -87,6 +87,8 @@ class SlateEngine:
         return self.view(self.flat_g, p)
 
     def tensor(self, name, shape, dtype=torch.float32):
+        if name == "z":      # the soft sample is not a by-product of the step (fused soft-max heads): written on request
+            _lib.check(self.L.ocrl_slate_soft_z(self.h, self.stream))
         p, n = ctypes.c_void_p(), ctypes.c_longlong()
         _lib.check(self.L.ocrl_slate_tensor(self.h, name.encode(), ctypes.byref(p), ctypes.byref(n)))
         cnt = 1

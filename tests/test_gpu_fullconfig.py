@@ -181,7 +181,7 @@ def test_full_config_against_oracle(tag, over, B):
     load_params(eng, P)
     eng.forward(obs.cuda(), tau, train=False, seed=1, noise=dev_noise(cfg, noise))
     torch.cuda.synchronize()
-    errs = compare_forward(tag, eng, cfg, r32, B)
+    errs = compare_forward(tag, eng, cfg, r32, B, noise, tau)
     assert errs["tokens_mismatch"] == 0
     for k in ("dvae_mse", "cross_entropy", "loss"):
         assert errs[k] < 1e-5, (k, errs[k])

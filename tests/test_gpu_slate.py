@@ -52,11 +52,17 @@ def site_masks(eng, cfg, B):
     return M
 
 
-def compare_forward(tag, eng, cfg, res, B):
+def compare_forward(tag, eng, cfg, res, B, noise, tau):
     S, E = cfg.obs_size, cfg.obs_size // 4
     T, N, V, K, D, d = E * E, S * S, cfg.vocab_size, cfg.num_slots, cfg.slot_size, cfg.d_model
     errs = {}
-    zl = torch.log_softmax(eng.tensor("zraw", (B, T, V)).cpu(), -1)
+    zraw = eng.tensor("zraw", (B, T, V)).double().cpu()
+    if not cfg.hard:
+        # soft samples: the head GEMM's epilogue leaves the Gumbel scores (logits + g1) / tau, not the logits (z is rebuilt from them on
+        # the fly); with the injected Exp(1) noise e1, g1 = -log(e1 + tiny), so the logits are recovered for the z_logits comparison
+        e1 = dev_noise(cfg, noise)["z"].double().cpu().reshape(B, T, V)
+        zraw = zraw * tau + torch.log(e1 + 1.17549435e-38)
+    zl = torch.log_softmax(zraw, -1)
     errs["z_logits"] = relerr(zl, res["z_logits"].permute(0, 2, 3, 1).reshape(B, T, V))
     errs["z"] = relerr(eng.tensor("z_st" if cfg.hard else "z", (B, T, V)), res["z"].permute(0, 2, 3, 1).reshape(B, T, V))
     tok = eng.tensor("tokens", (B, T), torch.int32).cpu().long()
@@ -127,7 +133,7 @@ def test_forward_backward_eval(tag, over, B):
     res = tr.loss_and_grads(obs, noise, step, None)
     eng.forward(obs.cuda(), tau, train=False, seed=1, noise=dev_noise(cfg, noise))
     torch.cuda.synchronize()
-    errs = compare_forward(tag, eng, cfg, res, B)
+    errs = compare_forward(tag, eng, cfg, res, B, noise, tau)
     assert errs["tokens_mismatch"] == 0
     for k in ("dvae_mse", "cross_entropy", "loss"):
         assert errs[k] < 1e-5, (k, errs[k])

@@ -2,7 +2,7 @@
 gemm.hip, not part of the product path."""
 import torch
 torch.backends.cuda.matmul.allow_tf32 = False
-SHAPES = [("proj NT", 131072, 192, 192, "nt"), ("ffn1 NT", 131072, 768, 192, "nt"), ("ffn2 NT", 131072, 192, 768, "nt"), ("head NT", 131072, 4096, 192, "nt"),
+SHAPES = [("proj NT", 131072, 192, 192, "nt"), ("qkv NT", 131072, 576, 192, "nt"), ("ffn1 NT", 131072, 768, 192, "nt"), ("ffn2dx NN", 131072, 768, 192, "nn"), ("projdx NN", 131072, 192, 192, "nn"), ("ffn2 NT", 131072, 192, 768, "nt"), ("head NT", 131072, 4096, 192, "nt"),
           ("headdx NN", 131072, 192, 4096, "nn"), ("samlp NT", 2097152, 64, 64, "nt"), ("dW TN 192", 192, 192, 131072, "tn"), ("dW TN 768x192", 768, 192, 131072, "tn"),
           ("dW TN 4096x192", 4096, 192, 131072, "tn")]
 for name, M, N, K, form in SHAPES:
