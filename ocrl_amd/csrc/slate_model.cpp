@@ -249,7 +249,7 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
         //   2 = forward and backward beside the slot-attention launches only (round 1's default, when slot attention left half the CUs idle)
         //   1 = whole dVAE branch beside encoder + decoder (per-kernel timings of both branches stop being comparable); 0 = single stream
         const char* e = getenv("OCRL_OVERLAP");
-        overlap_mode_ = e ? atoi(e) : 3;
+        overlap_mode_ = e ? atoi(e) : 5;
         if (overlap_mode_) {
             OCRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
             OCRL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -396,14 +396,23 @@ int SlateModel::pack_weights(hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // CNN encoder + slot attention (ocrs/common/models.py:96-107, slot_attn.py:147-161)
-int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, bool fork_dvae) {
+int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae) {
     const int B = in.B;
     const long long BN = (long long)B * N;
+    auto fork_here = [&]() -> int {
+        RC(fork_side(st));
+        std::swap(scratch_, scratch2_);
+        const int rc = fwd_dvae(in, side_);
+        std::swap(scratch_, scratch2_);
+        return rc;
+    };
+    if (fork_dvae == 2) RC(fork_here());
     RC(nchw_to_nhwc8_launch(in.obs, obs8_, B, cfg.obs_channels, S, S, st));
     RC(conv_layer_fwd(obs8_, cw_fwd_[0], P("_enc._encoder.0.m.bias"), e1_, B, S, S, 5, 8, 1, nullptr, nullptr, st));
     RC(conv_layer_fwd(e1_, cw_fwd_[1], P("_enc._encoder.1.m.bias"), e2_, B, S, S, 5, 64, 1, nullptr, nullptr, st));
     RC(conv_layer_fwd(e2_, cw_fwd_[2], P("_enc._encoder.2.m.bias"), e3_, B, S, S, 5, 64, 1, nullptr, nullptr, st));
     RC(conv_layer_fwd(e3_, cw_fwd_[3], P("_enc._encoder.3.bias"), e4_, B, S, S, 5, 64, 0, posmap_, nullptr, st));
+    if (fork_dvae == 3) RC(fork_here());
     RC(layernorm_fwd_launch(e4_, P("_slotattn.layer_norm.weight"), P("_slotattn.layer_norm.bias"), ln0_, ln0_mean_, ln0_rstd_, BN, C, st));
     RC(lin_fwd(ln0_, C, P("_slotattn.mlp.0.weight"), P("_slotattn.mlp.0.bias"), h1_, C, BN, C, C, 1, nullptr, 0, 0.f, 0, st));
     RC(lin_fwd(h1_, C, P("_slotattn.mlp.2.weight"), P("_slotattn.mlp.2.bias"), x_, C, BN, C, C, 0, nullptr, 0, 0.f, 0, st));
@@ -412,13 +421,7 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, bool fork_dvae
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
     a.xchg = sa_xchg_; a.parts = sa_parts_;
-    if (fork_dvae) {
-        RC(fork_side(st));
-        std::swap(scratch_, scratch2_);
-        const int rc = fwd_dvae(in, side_);
-        std::swap(scratch_, scratch2_);
-        RC(rc);
-    }
+    if (fork_dvae == 1) RC(fork_here());
     RC(slot_attn_launch(a, 0, st));
     return 0;
 }
@@ -552,7 +555,8 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
     // the dVAE branch (tokens, reconstruction loss) and the CNN encoder + slot attention are independent until the decoder:
     // the dVAE runs on the side stream, filling the CUs the one-workgroup-per-image slot-attention kernel leaves idle
     if (side_ && overlap_mode_ >= 2) {
-        RC(fwd_encoder(in, st, true));       // forks the dVAE forward right before the slot-attention launch
+        // forks the dVAE forward right before the slot-attention launch (modes 2, 3), at the start of the step (4) or after the convolutions (5)
+        RC(fwd_encoder(in, st, overlap_mode_ == 4 ? 2 : (overlap_mode_ == 5 ? 3 : 1)));
         RC(join_side(st));
     } else if (side_) {
         RC(fork_side(st));
@@ -655,18 +659,25 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         const unsigned site = SITE_BLK_BASE + 8 * b;
         const float* xin = (b == 0) ? emb_ : blk_[b - 1].x3;
         // ---- feed forward:  x3 = x2 + drop(W2 relu(W1 ln3 + b1) + b2)
-        Drop dr;
-        dr.p = p; dr.site = site + 4;
-        RC(lin_bwd_w(gx_, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d, 1.f, st, dr));
-        RC(lin_bwd_x(gx_, d, P(pre + "ffn.2.weight"), gf1_, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st, dr));
+        // the gradient entering a residual branch is dropout-backward(gx) of the branch's site: applied once into gbr_ and fed to both
+        // the weight-gradient and the input-gradient product (drawing the mask inside the products made each 40-90 % slower)
+        const float* gd = gx_;
+        auto drop_gx = [&](unsigned s_) -> int {
+            gd = gx_;
+            if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, s_, st)); gd = gbr_; }
+            return 0;
+        };
+        RC(drop_gx(site + 4));
+        RC(lin_bwd_w(gd, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d, 1.f, st));
+        RC(lin_bwd_x(gd, d, P(pre + "ffn.2.weight"), gf1_, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st));
         RC(lin_bwd_w(gf1_, 4 * d, k.ln3, d, G(pre + "ffn.0.weight"), G(pre + "ffn.0.bias"), BT, 4 * d, d, 1.f, st));
         RC(lin_bwd_x(gf1_, 4 * d, P(pre + "ffn.0.weight"), gt1_, d, BT, 4 * d, d, nullptr, 0, nullptr, 0, st));
         RC(layernorm_bwd_launch(gt1_, k.x2, k.ln3_mean, k.ln3_rstd, P(pre + "ffn_layer_norm.weight"), gx_, G(pre + "ffn_layer_norm.weight"), BT, d, 1, 0,
                                 scratch_, scratch_floats_, st));
         // ---- cross attention
-        dr.site = site + 3;
-        RC(lin_bwd_w(gx_, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st, dr));
-        RC(lin_bwd_x(gx_, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st, dr));   // d cao
+        RC(drop_gx(site + 3));
+        RC(lin_bwd_w(gd, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gd, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d cao
         RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, gt2_, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, scratch_, scratch_floats_, st));   // gt2 = d cq
         RC(lin_bwd_w(gt2_, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
         RC(lin_bwd_x(gt2_, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
@@ -677,9 +688,9 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         RC(layernorm_bwd_launch(gt1_, k.x1, k.ln2_mean, k.ln2_rstd, P(pre + "encoder_decoder_attn_layer_norm.weight"), gx_,
                                 G(pre + "encoder_decoder_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         // ---- causal self attention
-        dr.site = site + 1;
-        RC(lin_bwd_w(gx_, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st, dr));
-        RC(lin_bwd_x(gx_, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st, dr));   // gt1 = d ao
+        RC(drop_gx(site + 1));
+        RC(lin_bwd_w(gd, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(lin_bwd_x(gd, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt1 = d ao
         {
             AttnArgs a;
             a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH; a.ld = 3 * d;
@@ -856,7 +867,7 @@ int SlateModel::backward(hipStream_t st) {
     if (side_ && overlap_mode_ == 2) {
         RC(bwd_decoder(st));
         RC(bwd_encoder(st, true));           // forks the dVAE backward at the slot-attention launch, joins before the 5x5 convolutions
-    } else if (side_ && overlap_mode_ == 3) {
+    } else if (side_ && overlap_mode_ >= 3) {
         // the dVAE backward (many short 64-wide products) runs beside the transformer-decoder backward and is joined before the
         // slot-attention / convolution kernels, which then have the machine to themselves (their timings stay comparable)
         RC(fork_side(st));

@@ -85,7 +85,7 @@ private:
     int conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN, int cin_real,
                          hipStream_t st);
     int pack_weights(hipStream_t st);
-    int fwd_encoder(const StepInputs& in, hipStream_t st, bool fork_dvae = false);
+    int fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae = 0);
     int fwd_dvae(const StepInputs& in, hipStream_t st);
     int fwd_decoder(hipStream_t st, bool with_ce = true);
     int dvae_decode(int B, float* drecon, hipStream_t st, const float* zin = nullptr);
