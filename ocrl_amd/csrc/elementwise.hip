@@ -721,13 +721,28 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kernel(const float* __rest
     // row) straight into the staging tile the matrix products read; a thread then takes its own row from LDS.  Thread-per-row global
     // loads (64 different cache lines per instruction) were what bound this kernel.
     const int q0 = qb * 256 + wv * 64, dh4 = dh >> 2;
+    // All dh/4 loads of a lane are issued before the first LDS store (a rolled load -> store loop paid one memory round trip per
+    // 16 bytes: 2 x 12 round trips per workgroup, with two workgroups per CU to hide them).  (row, chunk) advance without divisions.
+    const int r_step = 64 / dh4, c_step = 64 - r_step * dh4;
     auto load_tile = [&](const float* src, float mul) {
-        for (int idx = lane; idx < 64 * dh4; idx += 64) {
-            const int r = idx / dh4, c4 = idx - r * dh4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q0 + r < T) v = *reinterpret_cast<const float4*>(src + (b * T + q0 + r) * d + hd * dh + 4 * c4);
-            float* dst = stg + r * CA_SW + CA_MAXK + 4 * c4;
-            dst[0] = v.x * mul; dst[1] = v.y * mul; dst[2] = v.z * mul; dst[3] = v.w * mul;
+        float4 tmp[CA_MAXDH / 4];
+        int r = lane / dh4, c4 = lane - r * dh4;
+#pragma unroll
+        for (int i = 0; i < CA_MAXDH / 4; ++i) {
+            tmp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < dh4 && q0 + r < T) tmp[i] = *reinterpret_cast<const float4*>(src + (b * T + q0 + r) * d + hd * dh + 4 * c4);
+            r += r_step; c4 += c_step;
+            if (c4 >= dh4) { c4 -= dh4; ++r; }
+        }
+        r = lane / dh4; c4 = lane - r * dh4;
+#pragma unroll
+        for (int i = 0; i < CA_MAXDH / 4; ++i) {
+            if (i < dh4) {
+                float* dst = stg + r * CA_SW + CA_MAXK + 4 * c4;
+                dst[0] = tmp[i].x * mul; dst[1] = tmp[i].y * mul; dst[2] = tmp[i].z * mul; dst[3] = tmp[i].w * mul;
+            }
+            r += r_step; c4 += c_step;
+            if (c4 >= dh4) { c4 -= dh4; ++r; }
         }
         __builtin_amdgcn_wave_barrier();
     };
