@@ -157,6 +157,92 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* 
         part[(size_t)blockIdx.x * 2 * F + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// 64-wide rows (the slot-attention input norm over B*H*W positions): one wave per row meant one 4-byte load per lane and two full wave
+// reductions per 256 bytes -- latency-bound at 2.4 TB/s.  Here 16 lanes own a row (float4 each), a wave works on 4 rows per pass and
+// has 4 passes (16 rows) in flight; the reductions are four xor-shuffles inside the 16-lane group.
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void layernorm_fwd64_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
+                                                              float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long long R) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4 = lane & 15, rsub = lane >> 4;
+    const long long row0 = ((long long)blockIdx.x * 4 + wv) * 16 + rsub;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long row = row0 + 4 * i;
+        v[i] = row < R ? *reinterpret_cast<const float4*>(x + row * 64 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 gg = *reinterpret_cast<const float4*>(g + c4 * 4), bb = *reinterpret_cast<const float4*>(bta + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long row = row0 + 4 * i;
+        const float mu = group16_sum((v[i].x + v[i].y) + (v[i].z + v[i].w)) * (1.0f / 64);
+        const float4 dd = make_float4(v[i].x - mu, v[i].y - mu, v[i].z - mu, v[i].w - mu);
+        const float rs = rsqrtf(group16_sum((dd.x * dd.x + dd.y * dd.y) + (dd.z * dd.z + dd.w * dd.w)) * (1.0f / 64) + 1e-5f);
+        if (row < R) {
+            *reinterpret_cast<float4*>(y + row * 64 + c4 * 4) =
+                make_float4(dd.x * rs * gg.x + bb.x, dd.y * rs * gg.y + bb.y, dd.z * rs * gg.z + bb.z, dd.w * rs * gg.w + bb.w);
+            if (c4 == 0) {
+                if (mean) mean[row] = mu;
+                if (rstd) rstd[row] = rs;
+            }
+        }
+    }
+}
+// backward, same layout; a block walks 64-row groups with stride gridDim.x and leaves its dgamma | dbeta partial in part[blk][128]
+__global__ __launch_bounds__(256) void layernorm_bwd64_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx,
+                                                              float* __restrict__ part, long long R, int accumulate) {
+    __shared__ float4 red[2][16][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4 = lane & 15, rsub = lane >> 4;
+    const float4 gg = *reinterpret_cast<const float4*>(g + c4 * 4);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+    for (long long grp = blockIdx.x; grp * 64 < R; grp += gridDim.x) {
+        const long long row0 = (grp * 4 + wv) * 16 + rsub;
+        float4 xv[4], yv[4];
+        float mu[4], rs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long row = row0 + 4 * i;
+            const bool ok = row < R;
+            xv[i] = ok ? *reinterpret_cast<const float4*>(x + row * 64 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            yv[i] = ok ? *reinterpret_cast<const float4*>(dy + row * 64 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mu[i] = ok ? mean[row] : 0.f;
+            rs[i] = ok ? rstd[row] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long row = row0 + 4 * i;
+            const float4 xh = make_float4((xv[i].x - mu[i]) * rs[i], (xv[i].y - mu[i]) * rs[i], (xv[i].z - mu[i]) * rs[i], (xv[i].w - mu[i]) * rs[i]);
+            dg.x += yv[i].x * xh.x; dg.y += yv[i].y * xh.y; dg.z += yv[i].z * xh.z; dg.w += yv[i].w * xh.w;
+            db.x += yv[i].x; db.y += yv[i].y; db.z += yv[i].z; db.w += yv[i].w;
+            const float4 d4 = make_float4(yv[i].x * gg.x, yv[i].y * gg.y, yv[i].z * gg.z, yv[i].w * gg.w);
+            const float s1 = group16_sum((d4.x + d4.y) + (d4.z + d4.w)) * (1.0f / 64);
+            const float s2 = group16_sum((d4.x * xh.x + d4.y * xh.y) + (d4.z * xh.z + d4.w * xh.w)) * (1.0f / 64);
+            if (row < R) {
+                float4 o = make_float4(rs[i] * (d4.x - s1 - xh.x * s2), rs[i] * (d4.y - s1 - xh.y * s2), rs[i] * (d4.z - s1 - xh.z * s2),
+                                       rs[i] * (d4.w - s1 - xh.w * s2));
+                float* dp = dx + row * 64 + c4 * 4;
+                if (accumulate) { const float4 a = *reinterpret_cast<const float4*>(dp); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                *reinterpret_cast<float4*>(dp) = o;
+            }
+        }
+    }
+    red[0][wv * 4 + rsub][c4] = dg;
+    red[1][wv * 4 + rsub][c4] = db;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int which = threadIdx.x >> 4, c = threadIdx.x & 15;
+        float4 a = red[which][0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 t = red[which][k][c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 128 + which * 64 + c * 4) = a;
+    }
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients etc.)
 // part[chunk][F] = sum over the chunk's rows of X[r][f]
 __global__ void colsum_kernel(const float* __restrict__ X, long long ld, float* __restrict__ part, long long R, int F, long long rows_per_chunk) {
@@ -1088,8 +1174,12 @@ int pixel_shuffle_launch(const float* in, float* out, int B, int h, int w, int C
 int layernorm_fwd_launch(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, long long R, int F, hipStream_t st) {
     OCRL_REQUIRE(F % 64 == 0 && F >= 64 && F <= 256, "layernorm: F must be 64..256, multiple of 64 (got %d)", F);
     dim3 grid(cdiv(R, 4)), blk(256);
+    const bool al16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)g | (uintptr_t)b) & 15) == 0;
     switch (F / 64) {
-        case 1: hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
+        case 1:
+            if (al16) hipLaunchKernelGGL(layernorm_fwd64_kernel, dim3((unsigned)cdiv(R, 64)), blk, 0, st, x, g, b, y, mean, rstd, R);
+            else hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, st, x, g, b, y, mean, rstd, R);
+            break;
         case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
         case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
         default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
@@ -1135,7 +1225,11 @@ int layernorm_bwd_launch(const float* dy, const float* x, const float* mean, con
     OCRL_REQUIRE(need + (size_t)8 * 2 * F <= ws_floats, "layernorm bwd: workspace too small");
     dim3 grid(nblk), blk(256);
     switch (F / 64) {
-        case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
+        case 1:
+            if (((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)g) & 15) == 0) && (((uintptr_t)ws) & 15) == 0)
+                hipLaunchKernelGGL(layernorm_bwd64_kernel, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx);
+            else hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx);
+            break;
         case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
         case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
         default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
