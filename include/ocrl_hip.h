@@ -78,7 +78,9 @@ int ocrl_slate_grad_norm(ocrl_slate* h, void* stream);
 /* device float[8]: [0] dvae_mse (mse with use_bcdec), [1] cross_entropy, [2] loss, [3] max|grad|, [4] mse of ocrl_slate_generate */
 float* ocrl_slate_metrics(const ocrl_slate* h);
 /* Named tensors of the last step ("slots" [B,K,D], "attn" [B,N,K], "recon" [B,S,S,4], "tokens"
- * (int32) [B,T], "zraw"/"z" [B,T,V], "feats" [B,N,64], "dec_out" [B,T,d], "pred", "mem", "emb",
+ * (int32) [B,T], "zraw" [B,T,V] (soft models: the Gumbel scores (logits + g)/tau until the backward overwrites them with d logits;
+ * hard=True: the raw logits), "z" [B,T,V] (see ocrl_slate_soft_z), "z_lse"/"ce_lse" [B,T], "feats" [B,N,64], "dec_out" [B,T,d],
+ * "pred" (the output-head logits), "mem", "emb",
  * "slots0", "sa_inputs") or any parameter name; count = capacity in elements at max_batch. */
 int ocrl_slate_tensor(const ocrl_slate* h, const char* name, float** ptr, long long* count);
 /* The soft Gumbel sample z = softmax((logits + g) / tau) of the last forward (ocrs/slate/slate_module.py:126, the `z` that
