@@ -1209,7 +1209,7 @@ int layernorm_fwd_launch(const float* x, const float* g, const float* b, float* 
 int colsum_launch(const float* X, long long ld, float* out, long long R, int F, int accumulate, float scale, float* ws, size_t ws_floats, hipStream_t st) {
     if (F % 4 == 0 && ld % 4 == 0 && F <= 1024 && F >= 4 && (((uintptr_t)X) & 15) == 0 && R >= 1024) {
         long long nchunk = 2048;
-        if (nchunk > R / 64) nchunk = R / 64;
+        if (nchunk > R / 8) nchunk = R / 8;          // >= 8 rows per chunk: a 2048-row partial table (LayerNorm gamma / beta) spreads over 256 workgroups, not 32
         if ((size_t)nchunk * F > ws_floats) nchunk = (long long)(ws_floats / F);
         if (nchunk >= 16) {
             const long long rpc = (R + nchunk - 1) / nchunk;
