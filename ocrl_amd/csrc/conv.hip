@@ -36,6 +36,12 @@ __global__ __launch_bounds__(256, (ConvCfg<KS, CIN>::WGS)) void conv_fwd_kernel(
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     int bid = blockIdx.x;
+    {
+        // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of tiles (whole images at the usual sizes) so
+        // that the halo rows two vertically adjacent tiles share are served by that XCD's L2 instead of being fetched twice
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int b = bid;
@@ -223,7 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
     float* dYs = smem;                     // [TH*TW][COUT]
     float* Xs = smem + TH * TW * COUT;     // [TH][HW_][CIN]
 
-    const int ky = blockIdx.y;
+    // (chunk worker, kernel row) from the linear dispatch index, re-dealt so that the KS workgroups that stream the same pixel tiles
+    // for different kernel rows sit on one XCD (the dispatcher deals linear ids round-robin to the 8 XCDs): their X / dY tiles then
+    // come out of that XCD's L2 four times out of five (PMC: 5.4 GB per launch for 1.07 GB of operands before)
+    int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    {
+        const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, x = lin & 7, y = lin >> 3;
+        lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int cx = lin / (int)gridDim.y, ky = lin % (int)gridDim.y;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = tiles_x * tiles_y * p.B;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -269,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
             if (idx < XT && y >= 0 && y < p.H && x >= 0 && x < p.W) rx[i] = *reinterpret_cast<const float4*>(gx + ((size_t)y * p.W + x) * CIN + c4 * 4);
         }
     };
-    if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if ((int)cx < ntiles) gload(cx);
+    for (int t = cx; t < ntiles; t += gridDim.x) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < NDY; ++i) {
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
         }
     }
     // ---- partial slab [slab][ky*KS+kx][co][CIN]
-    const int slab = blockIdx.x * KSPLIT + ksp;
+    const int slab = cx * KSPLIT + ksp;
     float* out = p.part + ((size_t)slab * KS * KS + ky * KS) * COUT * CIN;
     if (CIN == 64 || li < CIN) {
 #pragma unroll
