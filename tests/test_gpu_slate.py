@@ -319,8 +319,9 @@ def test_autoregressive_generation_matches_oracle(tag, over, B):
 
 
 def test_side_stream_overlap_matches_single_stream(monkeypatch):
-    """OCRL_OVERLAP=1 / 2 run the dVAE branch on a side stream (fork/join with events; 2 = beside the slot-attention kernels only):
-    same losses and gradients"""
+    """OCRL_OVERLAP=1..5 run the dVAE branch on a side stream (fork/join with events; 2 = beside the slot-attention kernels only, 3 = backward
+    beside the decoder backward, 4 / 5 = forward forked at the start of the step / after the encoder convolutions; 5 is the default):
+    same losses and gradients -- since every reduction has a fixed order, bit for bit"""
     cfg = O.default_cfg(**MID)
     B = 3
     P = O.formula_params(cfg)
@@ -328,7 +329,7 @@ def test_side_stream_overlap_matches_single_stream(monkeypatch):
     obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=g).cuda()
     noise = dev_noise(cfg, O.make_noise(cfg, B, 9))
     outs = []
-    for flag in ("0", "1", "2"):
+    for flag in ("0", "1", "2", "3", "4", "5"):
         monkeypatch.setenv("OCRL_OVERLAP", flag)
         eng = make_engine(cfg, B)
         load_params(eng, P)
@@ -341,6 +342,7 @@ def test_side_stream_overlap_matches_single_stream(monkeypatch):
     for o in outs[1:]:
         assert torch.allclose(outs[0][0][:3], o[0][:3], rtol=1e-6)
         assert (outs[0][1] - o[1]).abs().max() <= 1e-5 * gmax
+        assert torch.equal(outs[0][1], o[1])          # the stream a kernel runs on does not change its arithmetic
 
 
 def test_full_size_batch_additivity():
