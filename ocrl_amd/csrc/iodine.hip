@@ -490,6 +490,34 @@ __global__ void io_im2col_kernel(const float* __restrict__ x, float* __restrict_
     }
     col[i] = v;
 }
+// same, on a (row chunk, oy, image) grid with 32-bit index arithmetic and one float4 store per thread (ldc % 4 == 0); the kernel above
+// spends its time in five 64-bit divisions per element
+__global__ __launch_bounds__(256) void io_im2col4_kernel(const float* __restrict__ x, float* __restrict__ col, int C, int Hi, int Wi, int Ho, int Wo, int ldc) {
+    const int L4 = ldc >> 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Wo * L4) return;
+    const int ox = e / L4, j4 = e - ox * L4;
+    const int oy = blockIdx.y;
+    const long long b = blockIdx.z;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + b * Hi * Wi * C;
+    if ((C & 3) == 0) {                                   // four consecutive columns = four channels of one tap
+        const int j = j4 * 4, tap = j / C, c = j - tap * C;
+        const int y = 2 * oy - 1 + tap / 3, xx = 2 * ox - 1 + tap % 3;
+        if (tap < 9 && y >= 0 && y < Hi && xx >= 0 && xx < Wi) {
+            const float4 t = *reinterpret_cast<const float4*>(xb + ((size_t)y * Wi + xx) * C + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j4 * 4 + k, tap = j / C, c = j - tap * C;
+            const int y = 2 * oy - 1 + tap / 3, xx = 2 * ox - 1 + tap % 3;
+            if (tap < 9 && y >= 0 && y < Hi && xx >= 0 && xx < Wi) v[k] = xb[((size_t)y * Wi + xx) * C + c];
+        }
+    }
+    *reinterpret_cast<float4*>(col + ((b * Ho + oy) * (long long)Wo) * ldc + (long long)e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
 // dx[b][y][x][c] = (sum over the windows that contain the pixel of dcol) * elu'(act)   (act = this tensor's ELU output, nullable)
 __global__ void io_col2im_kernel(const float* __restrict__ dcol, const float* __restrict__ act, float* __restrict__ dx, long long n, int C, int Hi,
                                  int Wi, int Ho, int Wo, int ldc) {
@@ -508,6 +536,30 @@ __global__ void io_col2im_kernel(const float* __restrict__ dcol, const float* __
             a += dcol[((b * Ho + (ty >> 1)) * Wo + (tx >> 1)) * ldc + (ky * 3 + kx) * C + c];
         }
     }
+    if (act) { const float m = act[i]; a = m > 0.f ? a : a * (m + 1.f); }
+    dx[i] = a;
+}
+// same on a (row chunk, y, image) grid with 32-bit index arithmetic
+__global__ __launch_bounds__(256) void io_col2im3_kernel(const float* __restrict__ dcol, const float* __restrict__ act, float* __restrict__ dx, int C,
+                                                         int Hi, int Wi, int Ho, int Wo, int ldc) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Wi * C) return;
+    const int x = e / C, c = e - x * C;
+    const int y = blockIdx.y;
+    const long long b = blockIdx.z;
+    float a = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = y + 1 - ky;
+        if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = x + 1 - kx;
+            if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+            a += dcol[((b * Ho + (ty >> 1)) * Wo + (tx >> 1)) * ldc + (ky * 3 + kx) * C + c];
+        }
+    }
+    const long long i = ((b * Hi + y) * (long long)Wi) * C + e;
     if (act) { const float m = act[i]; a = m > 0.f ? a : a * (m + 1.f); }
     dx[i] = a;
 }
@@ -724,14 +776,20 @@ int io_latent_launch(const float* mu, const float* ls, const float* eps, const f
 int io_im2col_launch(const float* x, float* col, long long Bn, int C, int Hi, int Wi, int ldc, hipStream_t st) {
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     const long long rows = Bn * Ho * Wo;
-    hipLaunchKernelGGL(io_im2col_kernel, IO_GRID(rows * ldc), 0, st, x, col, rows, C, Hi, Wi, Ho, Wo, ldc);
+    if ((ldc & 3) == 0 && (((uintptr_t)col) & 15) == 0 && (((uintptr_t)x) & 15) == 0 && Ho <= 65535 && Bn <= 65535)
+        hipLaunchKernelGGL(io_im2col4_kernel, dim3((unsigned)((Wo * (ldc >> 2) + 255) / 256), (unsigned)Ho, (unsigned)Bn), dim3(256), 0, st, x, col, C, Hi, Wi, Ho, Wo, ldc);
+    else
+        hipLaunchKernelGGL(io_im2col_kernel, IO_GRID(rows * ldc), 0, st, x, col, rows, C, Hi, Wi, Ho, Wo, ldc);
     OCRL_CHECK_LAUNCH("io_im2col");
     return 0;
 }
 int io_col2im_launch(const float* dcol, const float* act, float* dx, long long Bn, int C, int Hi, int Wi, int ldc, hipStream_t st) {
     const int Ho = (Hi - 1) / 2 + 1, Wo = (Wi - 1) / 2 + 1;
     const long long n = Bn * Hi * Wi * C;
-    hipLaunchKernelGGL(io_col2im_kernel, IO_GRID(n), 0, st, dcol, act, dx, n, C, Hi, Wi, Ho, Wo, ldc);
+    if (Hi <= 65535 && Bn <= 65535)
+        hipLaunchKernelGGL(io_col2im3_kernel, dim3((unsigned)((Wi * C + 255) / 256), (unsigned)Hi, (unsigned)Bn), dim3(256), 0, st, dcol, act, dx, C, Hi, Wi, Ho, Wo, ldc);
+    else
+        hipLaunchKernelGGL(io_col2im_kernel, IO_GRID(n), 0, st, dcol, act, dx, n, C, Hi, Wi, Ho, Wo, ldc);
     OCRL_CHECK_LAUNCH("io_col2im");
     return 0;
 }
