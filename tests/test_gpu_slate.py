@@ -215,6 +215,33 @@ def test_encode_matches_forward_slots():
     assert torch.allclose(a, torch.ones_like(a), atol=1e-5)      # softmax over slots sums to one at every position
 
 
+def test_soft_sample_on_request():
+    """The fused heads keep the Gumbel scores, not z: ocrl_slate_soft_z rebuilds z = softmax(scores) between forward and backward
+    (get_loss(with_rep=True), slate_module.py:239-241) and refuses once the backward has overwritten the scores with their gradient;
+    the hard sample's tokens are the arg-max of the second Gumbel draw, i.e. distributed like z's underlying categorical."""
+    cfg = O.default_cfg(**V4096)
+    B = 2
+    eng = make_engine(cfg, B)
+    load_params(eng, O.formula_params(cfg))
+    S = cfg.obs_size
+    T, V = (S // 4) ** 2, cfg.vocab_size
+    obs = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(3)).cuda()
+    noise = O.make_noise(cfg, B, 11)
+    tau = 0.7
+    eng.forward(obs, tau, train=False, seed=2, noise=dev_noise(cfg, noise))
+    scores = eng.tensor("zraw", (B, T, V)).clone()
+    lse = eng.tensor("z_lse", (B, T)).clone()
+    z = eng.tensor("z", (B, T, V)).clone()
+    assert torch.allclose(lse.double(), torch.logsumexp(scores.double(), -1), atol=1e-5)
+    assert relerr(z, torch.softmax(scores.double(), -1)) < 2e-6
+    e2 = dev_noise(cfg, noise)["z_hard"]
+    hard = ((scores * tau + torch.log(dev_noise(cfg, noise)["z"] + 1.17549435e-38)) - torch.log(e2 + 1.17549435e-38)).argmax(-1)   # logits + g2
+    assert (hard.cpu() == eng.tensor("tokens", (B, T), torch.int32).cpu().long()).float().mean() > 0.999
+    eng.backward()
+    with pytest.raises(RuntimeError, match="soft_z"):
+        eng.tensor("z", (B, T, V))
+
+
 def test_device_rng_statistics():
     """no injected noise: Gumbel / slot noise / dropout come from the device RNG; check determinism per seed,
     sensitivity to the seed, and that z rows are distributions"""
