@@ -766,7 +766,10 @@ int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
     RC(lin_bwd_w(gmap_, C, gridT_, 4, G("_enc_pos.channels_map.weight"), G("_enc_pos.channels_map.bias"), N, C, 4, 1.f, st));
     if (fork_dvae) RC(join_side(st));
     // ---- CNN encoder, last layer first
-    RC(conv_layer_wgrad(e3_, gB_, G("_enc._encoder.3.weight"), G("_enc._encoder.3.bias"), B, S, S, 5, 64, 64, st));
+    // the last layer's bias gradient is the column sum of the per-position sums gmap_ just taken for the positional embedding (4 MB),
+    // not another pass over the [B*N, 64] gradient (537 MB)
+    RC(colsum_launch(gmap_, C, G("_enc._encoder.3.bias"), N, C, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(conv_layer_wgrad(e3_, gB_, G("_enc._encoder.3.weight"), nullptr, B, S, S, 5, 64, 64, st));
     RC(conv_layer_fwd(gB_, cw_bwd_[3], nullptr, gA_, B, S, S, 5, 64, 0, nullptr, e3_, st));                       // gA = d e3 (pre-relu)
     RC(conv_layer_wgrad(e2_, gA_, G("_enc._encoder.2.m.weight"), G("_enc._encoder.2.m.bias"), B, S, S, 5, 64, 64, st));
     RC(conv_layer_fwd(gA_, cw_bwd_[2], nullptr, gB_, B, S, S, 5, 64, 0, nullptr, e2_, st));
