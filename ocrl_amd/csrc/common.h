@@ -51,11 +51,16 @@ __host__ __device__ inline uint32_t rng_mix32(uint32_t x) {
 }
 
 // 64 random bits for the group of four consecutive elements idx4 = element_index / 4 at `site`.
-__host__ __device__ inline uint2 rng_bits4(uint64_t seed, uint32_t site, uint64_t idx4) {
-    // key: uniform over a launch (scalar work); the high counter bits enter here so that >2^32 groups do not repeat
-    const uint32_t key = rng_mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ rng_mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu * ((uint32_t)(idx4 >> 32) + 1u));
-    const uint32_t c = (uint32_t)idx4 ^ key;
+// key: uniform over a launch (scalar work); the high counter bits enter here so that >2^32 groups do not repeat
+__host__ __device__ inline uint32_t rng_key(uint64_t seed, uint32_t site, uint32_t idx4_hi) {
+    return rng_mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ rng_mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu * (idx4_hi + 1u));
+}
+__host__ __device__ inline uint2 rng_bits4_keyed(uint32_t key, uint32_t idx4_lo) {
+    const uint32_t c = idx4_lo ^ key;
     return make_uint2(rng_mix32(c), rng_mix32(c ^ 0x68E31DA4u) + key);
+}
+__host__ __device__ inline uint2 rng_bits4(uint64_t seed, uint32_t site, uint64_t idx4) {
+    return rng_bits4_keyed(rng_key(seed, site, (uint32_t)(idx4 >> 32)), (uint32_t)idx4);
 }
 
 // keep decision for element e (0..3) of a group: 16-bit uniform >= thresh, thresh = round(p * 65536)

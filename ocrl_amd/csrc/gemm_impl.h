@@ -379,22 +379,29 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                     }
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                     if (EPI == 2) {
-                        float4 ea = make_float4(1.f, 1.f, 1.f, 1.f), eb = ea;
+                        float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la;      // log(E + tiny) of the two draws: g = -log(E + tiny)
                         if (ok) {
                             const uint64_t idx = (uint64_t)row * (uint64_t)p.N + col;
                             if (p.e1) {
-                                ea = *reinterpret_cast<const float4*>(p.e1 + idx);
-                                eb = *reinterpret_cast<const float4*>(p.e2 + idx);
+                                const float4 ea = *reinterpret_cast<const float4*>(p.e1 + idx), eb = *reinterpret_cast<const float4*>(p.e2 + idx);
+                                la = make_float4(__logf(ea.x + TINYF_G), __logf(ea.y + TINYF_G), __logf(ea.z + TINYF_G), __logf(ea.w + TINYF_G));
+                                lb = make_float4(__logf(eb.x + TINYF_G), __logf(eb.y + TINYF_G), __logf(eb.z + TINYF_G), __logf(eb.w + TINYF_G));
                             } else {
-                                const uint2 b0 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx), b1 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx + 1);
-                                const uint2 b2 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx + 2), b3 = rng_bits4(p.e_seed, SITE_GUMBEL_Z, idx + 3);
-                                ea = make_float4(-__logf(u01_24(b0.x)), -__logf(u01_24(b1.x)), -__logf(u01_24(b2.x)), -__logf(u01_24(b3.x)));
-                                eb = make_float4(-__logf(u01_24(b0.y)), -__logf(u01_24(b1.y)), -__logf(u01_24(b2.y)), -__logf(u01_24(b3.y)));
+                                // the draws of gumbel_softmax_kernel (rng_bits4 at the element index), with the key taken once per four
+                                // elements.  The + tiny guard is live: the largest 24-bit uniform rounds to 1.0f, E = -log(1) = 0 (about 64 of
+                                // the 10^9 draws of a step at B = 128)
+                                const uint32_t key = rng_key(p.e_seed, SITE_GUMBEL_Z, (uint32_t)(idx >> 32)), lo = (uint32_t)idx;
+                                const uint2 b0 = rng_bits4_keyed(key, lo), b1 = rng_bits4_keyed(key, lo + 1), b2 = rng_bits4_keyed(key, lo + 2),
+                                            b3 = rng_bits4_keyed(key, lo + 3);
+                                la = make_float4(__logf(TINYF_G - __logf(u01_24(b0.x))), __logf(TINYF_G - __logf(u01_24(b1.x))),
+                                                 __logf(TINYF_G - __logf(u01_24(b2.x))), __logf(TINYF_G - __logf(u01_24(b3.x))));
+                                lb = make_float4(__logf(TINYF_G - __logf(u01_24(b0.y))), __logf(TINYF_G - __logf(u01_24(b1.y))),
+                                                 __logf(TINYF_G - __logf(u01_24(b2.y))), __logf(TINYF_G - __logf(u01_24(b3.y))));
                             }
                         }
-                        // hard sample: (l + g2) / tau, first maximum
-                        const float h0 = (v.x - __logf(eb.x + TINYF_G)) * p.e_scale, h1 = (v.y - __logf(eb.y + TINYF_G)) * p.e_scale;
-                        const float h2 = (v.z - __logf(eb.z + TINYF_G)) * p.e_scale, h3 = (v.w - __logf(eb.w + TINYF_G)) * p.e_scale;
+                        // hard sample: first maximum of l + g2 (the factor 1/tau > 0 does not move it, and the segment maxima are only
+                        // compared with one another)
+                        const float h0 = v.x - lb.x, h1 = v.y - lb.y, h2 = v.z - lb.z, h3 = v.w - lb.w;
                         float b = h0; int bi = col;
                         if (h1 > b) { b = h1; bi = col + 1; }
                         if (h2 > b) { b = h2; bi = col + 2; }
@@ -408,8 +415,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                         }
                         if (b > hb[ps]) { hb[ps] = b; hi[ps] = bi; }          // later patches hold higher columns: only a strictly larger value wins
                         // soft sample scores
-                        v.x = (v.x - __logf(ea.x + TINYF_G)) * p.e_scale; v.y = (v.y - __logf(ea.y + TINYF_G)) * p.e_scale;
-                        v.z = (v.z - __logf(ea.z + TINYF_G)) * p.e_scale; v.w = (v.w - __logf(ea.w + TINYF_G)) * p.e_scale;
+                        v.x = (v.x - la.x) * p.e_scale; v.y = (v.y - la.y) * p.e_scale; v.z = (v.z - la.z) * p.e_scale; v.w = (v.w - la.w) * p.e_scale;
                     }
                     float lm = cok ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : -INFINITY;
 #pragma unroll

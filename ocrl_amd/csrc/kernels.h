@@ -47,7 +47,7 @@ struct GemmArgs {
     // epilogue modes (128x128 tiles, k-contiguous A, N % 4 == 0, no split-k / batches):
     //   1: C = alpha*acc (+bias) and per (row, 64-column segment) soft-max statistics  stat[(row*nseg + seg)*2 + {0,1}] = (max, sum exp(v - max))
     //   2: Gumbel head: l = acc + bias;  C = (l + g1) * e_scale  with statistics as in 1;  the hard sample's segment maximum of
-    //      (l + g2) * e_scale and its column go to hstat / hidx.  g = -log(E + tiny), E from e1 / e2 (injected Exp(1) noise, [M,N]) or
+    //      l + g2 and its column go to hstat / hidx.  g = -log(E + tiny), E from e1 / e2 (injected Exp(1) noise, [M,N]) or
     //      from the counter RNG (e_seed, the same draws as gumbel_softmax_kernel)
     //   3: soft-max backward: C = exp(mask - e_lse[row]) * (acc - e_rowvec[row]) * e_scale   (mask = the stored scores; C may alias mask)
     int epi_mode = 0;
