@@ -109,6 +109,7 @@ SlateModel::SlateModel(const SlateConfig& c) : cfg(c) {
 SlateModel::~SlateModel() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_tokens_) (void)hipEventDestroy(ev_tokens_);
     if (side_) (void)hipStreamDestroy(side_);
 }
 
@@ -254,6 +255,7 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
             OCRL_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
             OCRL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
             OCRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+            OCRL_HIP(hipEventCreateWithFlags(&ev_tokens_, hipEventDisableTiming));
         }
     }
     // static tables
@@ -452,6 +454,9 @@ int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
     RC(lin_fwd(de_[6], 64, P("_dvae._encoder.7.weight"), P("_dvae._encoder.7.bias"), zraw_, V, BT, V, 64, 0, nullptr, 0, 0.f, 0, st));
     RC(gumbel_softmax_launch(zraw_, in.noise_z, in.noise_zh, z_, tokens_, BT, V, in.tau, in.seed, st, cfg.hard ? zdec_ : nullptr));
     }
+    // the transformer decoder only needs the tokens: it may start on the main stream while the dVAE decoder and the reconstruction loss
+    // are still running here (tokens_early mode of forward())
+    if (side_ && st == side_ && ev_tokens_) OCRL_HIP(hipEventRecord(ev_tokens_, st));
     RC(dvae_decode(B, drecon_, st));
     return 0;
 }
@@ -557,6 +562,16 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
     if (side_ && overlap_mode_ >= 2) {
         // forks the dVAE forward right before the slot-attention launch (modes 2, 3), at the start of the step (4) or after the convolutions (5)
         RC(fwd_encoder(in, st, overlap_mode_ == 4 ? 2 : (overlap_mode_ == 5 ? 3 : 1)));
+        if (overlap_mode_ >= 3 && !getenv("OCRL_TOKENS_LATE")) {
+            // wait for the tokens only; the rest of the dVAE branch (its decoder, the reconstruction loss) overlaps the transformer decoder
+            OCRL_HIP(hipStreamWaitEvent(st, ev_tokens_, 0));
+            RC(fwd_decoder(st));
+            RC(join_side(st));
+            RC(copy_launch(metrics_ + 0, metrics_ + 2, 1, st));
+            RC(axpy_launch(metrics_ + 1, metrics_ + 2, 1, 1.f, st));      // loss = dvae_mse + cross_entropy
+            have_fwd_ = true;
+            return 0;
+        }
         RC(join_side(st));
     } else if (side_) {
         RC(fork_side(st));

@@ -121,7 +121,7 @@ private:
     float* scratch2_ = nullptr;           // scratch of the dVAE branch when it runs on the side stream
     int overlap_mode_ = 0;                // OCRL_OVERLAP: 0 off, 1 whole dVAE branch beside encoder + decoder, 2 dVAE beside the slot-attention kernels only
     hipStream_t side_ = nullptr;          // dVAE forward / backward overlap the encoder + decoder work (independent branches)
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_tokens_ = nullptr;
     int fork_side(hipStream_t st);
     int join_side(hipStream_t st);
     float *zstat_ = nullptr, *zhstat_ = nullptr, *zlse_ = nullptr, *zdot_ = nullptr, *cestat_ = nullptr, *celse_ = nullptr, *cepart_ = nullptr;
