@@ -36,6 +36,8 @@ typedef struct ocrl_slate_config {
     int hard;                                   /* ocr_config.hard: straight-through Gumbel sample into the dVAE decoder */
 } ocrl_slate_config;
 
+/* sizeof(ocrl_slate_config) as this library was built: a binding checks its own struct against it before ocrl_slate_create */
+size_t ocrl_slate_config_size(void);
 int ocrl_slate_create(const ocrl_slate_config* cfg, ocrl_slate** out);
 void ocrl_slate_destroy(ocrl_slate* h);
 

@@ -35,6 +35,9 @@ def lib():
     p = c_void_p
     L.ocrl_last_error.restype = c_char_p
     L.ocrl_abi_version.restype = c_int
+    L.ocrl_slate_config_size.restype = c_size_t
+    if L.ocrl_slate_config_size() != ctypes.sizeof(SlateConfig):
+        raise RuntimeError(f"libocrl_hip.so: ocrl_slate_config is {L.ocrl_slate_config_size()} bytes, this binding's SlateConfig {ctypes.sizeof(SlateConfig)}")
     L.ocrl_slate_create.argtypes = [POINTER(SlateConfig), POINTER(p)]
     L.ocrl_slate_destroy.argtypes = [p]
     L.ocrl_slate_destroy.restype = None

@@ -38,6 +38,8 @@ int ocrl_obs_u8_to_f32(const unsigned char* obs_hwc, float* obs_chw, int B, int 
 }
 int ocrl_abi_version(void) { return OCRL_ABI_VERSION; }
 
+size_t ocrl_slate_config_size(void) { return sizeof(ocrl_slate_config); }
+
 int ocrl_slate_create(const ocrl_slate_config* c, ocrl_slate** out) {
     if (!c || !out) { ocrl_set_error("ocrl_slate_create: null argument"); return 1; }
     if (c->obs_size < 8 || c->obs_size % 4 || c->vocab_size < 256 || c->num_slots < 1 || c->num_iterations < 1 || c->max_batch < 1 ||

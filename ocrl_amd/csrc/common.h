@@ -40,7 +40,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 
 // ---- counter-based RNG: stateless, so forward and backward regenerate the same dropout decisions without storing masks.
 // 64 bits per call from two passes of a 32-bit avalanche mixer (two multiplies and three xor-shifts each; the "lowbias32" constants,
-// bias 0.17 %) over the element counter xor a per-(seed, site) key.  Round 1 used Philox-2x32-7 (14 quarter-rate integer multiplies per
+// bias 0.17 %) over the element counter xor a per-(seed, site) key, with the key added once more inside the mixer (rng_mix32k).  Round 1 used Philox-2x32-7 (14 quarter-rate integer multiplies per
 // call); this form needs 4 (measured: +0.4 % images/s — the Gumbel kernel turned out to be bound by its logs and exp, not the draws).
 // tests/test_gpu_determinism.py::test_device_rng_quality checks rates, serial and cross-site / cross-seed correlations.
 __host__ __device__ inline uint32_t rng_mix32(uint32_t x) {
@@ -55,9 +55,21 @@ __host__ __device__ inline uint32_t rng_mix32(uint32_t x) {
 __host__ __device__ inline uint32_t rng_key(uint64_t seed, uint32_t site, uint32_t idx4_hi) {
     return rng_mix32((uint32_t)seed ^ (site * 0x9E3779B9u)) ^ rng_mix32((uint32_t)(seed >> 32) + 0x85EBCA6Bu * (idx4_hi + 1u));
 }
+// The key enters twice: xor-ed into the counter and, through a second word derived from it, ADDED between the mixer's two multiplies.
+// With the xor alone every (seed, site) stream was the same fixed permutation of the counter, translated: stream A at group i equalled
+// stream B at group i ^ (kA ^ kB), so two steps or sites could share a whole noise field as a block permutation.  The addition after the
+// first multiply does not commute with the xor-translate (tests/test_gpu_determinism.py::test_device_rng_streams_are_not_translates).
+__host__ __device__ inline uint32_t rng_mix32k(uint32_t x, uint32_t k2) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x += k2;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
 __host__ __device__ inline uint2 rng_bits4_keyed(uint32_t key, uint32_t idx4_lo) {
     const uint32_t c = idx4_lo ^ key;
-    return make_uint2(rng_mix32(c), rng_mix32(c ^ 0x68E31DA4u) + key);
+    const uint32_t k2 = key * 0x9E3779B9u + 0x7F4A7C15u;      // uniform over a launch: scalar work
+    return make_uint2(rng_mix32k(c, k2), rng_mix32k(c ^ 0x68E31DA4u, k2) + key);
 }
 __host__ __device__ inline uint2 rng_bits4(uint64_t seed, uint32_t site, uint64_t idx4) {
     return rng_bits4_keyed(rng_key(seed, site, (uint32_t)(idx4 >> 32)), (uint32_t)idx4);

@@ -244,11 +244,15 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     named_.clear();
     layout_workspace(true);
     if (!side_) {
-        // OCRL_OVERLAP (default 3): the dVAE branch (many short 64-wide products that do not fill the machine) runs on a side stream.
-        //   3 = forward beside the slot-attention launches, backward beside the transformer-decoder backward; joined before the 5x5
-        //       convolutions and the slot-attention backward, so those never share the GPU and their timings stay comparable
+        // OCRL_OVERLAP (default 5): the dVAE branch (many short 64-wide products that do not fill the machine) runs on a side stream.
+        //   5 = forward forked right after the encoder convolutions (beside the input LayerNorm / MLP and the slot-attention chain),
+        //       backward beside the transformer-decoder backward and joined before the slot-attention backward and the 5x5
+        //       convolutions, so those never share the GPU and their timings stay comparable
+        //   4 = as 5 with the forward forked at the start of the step (beside the encoder convolutions)
+        //   3 = as 5 with the forward forked at the slot-attention launches
         //   2 = forward and backward beside the slot-attention launches only (round 1's default, when slot attention left half the CUs idle)
         //   1 = whole dVAE branch beside encoder + decoder (per-kernel timings of both branches stop being comparable); 0 = single stream
+        // In modes 3-5 the main stream waits for the dVAE tokens only (OCRL_TOKENS_LATE=1 restores the full join before the decoder).
         const char* e = getenv("OCRL_OVERLAP");
         overlap_mode_ = e ? atoi(e) : 5;
         if (overlap_mode_) {

@@ -119,7 +119,7 @@ private:
     float *scratch_ = nullptr;            // transient: split-k slabs, column-sum partials, wgrad slabs
     size_t scratch_floats_ = 0;
     float* scratch2_ = nullptr;           // scratch of the dVAE branch when it runs on the side stream
-    int overlap_mode_ = 0;                // OCRL_OVERLAP: 0 off, 1 whole dVAE branch beside encoder + decoder, 2 dVAE beside the slot-attention kernels only
+    int overlap_mode_ = 0;                // OCRL_OVERLAP 0..5 (default 5), described where it is read in SlateModel::bind
     hipStream_t side_ = nullptr;          // dVAE forward / backward overlap the encoder + decoder work (independent branches)
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_tokens_ = nullptr;
     int fork_side(hipStream_t st);

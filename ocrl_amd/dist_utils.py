@@ -58,6 +58,8 @@ def allreduce_grads_(flat_g):
     if dist is None:
         return 1.0
     if os.environ.get("OCRL_COMM", "") == "cabi" and flat_g.is_cuda:
+        if _cabi is not None and (_cabi.rank, _cabi.world) != (dist.get_rank(), dist.get_world_size()):
+            shutdown()          # the process group was destroyed and re-initialised with another shape: the old communicator is stale
         if _cabi is None:
             _cabi = CabiComm(dist)
         _cabi.allreduce_(flat_g)

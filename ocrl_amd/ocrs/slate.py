@@ -39,6 +39,12 @@ def linear_warmup(step, start_value, final_value, start_step, final_step):
 
 def _dims(ocr_config, env_config):
     sa = ocr_config.slotattr
+    heads = int(getattr(sa, "num_slot_heads", 1))
+    if heads != 1:
+        # ocrs/common/slot_attn.py:54-92 splits q/k/v into `heads` groups and takes the softmax over heads*slots columns; the HIP
+        # slot-attention kernels implement the single-head form every shipped configuration uses (configs/ocr/slate.yaml:21)
+        raise NotImplementedError(f"ocrl_amd: ocr.slotattr.num_slot_heads={heads} is not supported by the HIP backend (only 1); "
+                                  "the reference's multi-head slot attention (ocrs/common/slot_attn.py:54-92) is not built")
     return SimpleNamespace(
         obs_size=int(env_config.obs_size), obs_channels=int(env_config.obs_channels),
         vocab_size=int(ocr_config.dvae.vocab_size), d_model=int(ocr_config.dvae.d_model), cnn_hidden=int(ocr_config.cnn.hidden_size),
@@ -252,8 +258,14 @@ class SLATE_Module(nn.Module):
         self._injected_noise = noise
 
     def _next_seed(self):
-        self._step_seed += 1
-        return (self._seed << 32) + self._step_seed
+        """device-RNG stream id of the next forward.  update() sets the counter to 2*step, so a training step draws from the odd id
+        2*step + 1; every further forward before the next update() (a validation pass of any length) moves on in steps of 2 from a
+        separate high-bit range, so it never lands on a training step's stream"""
+        first = (self._step_seed & 1) == 0
+        self._step_seed += 1 if first else 2
+        if first:
+            return (self._seed << 32) + self._step_seed
+        return (self._seed << 32) + (1 << 31) + self._step_seed
 
     def _attns_image(self, B):
         K, S = self._num_slots, self._obs_size
@@ -439,7 +451,9 @@ class SLATE(Base):
         """ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74: schedules -> loss -> backward ->
         [gradient all-reduce over RCCL when torch.distributed is initialised] -> inf-norm clip -> Adam."""
         self._module.update_tau(step)
-        self._module._step_seed = int(step) * 16      # noise / dropout streams are a function of (seed, rank, global step): a resumed run replays nothing
+        # noise / dropout streams are a function of (seed, rank, global step): a resumed run replays nothing.  Training steps take the
+        # even slots of the counter; get_loss() calls outside update() (validation passes, samples) continue on the odd ones
+        self._module._step_seed = int(step) * 2
         lr = self._config.learning
         warm = linear_warmup(step, 0, 1, 0, lr.lr_warmup_steps)
         decay = math.exp(step / lr.lr_half_life * math.log(0.5))

@@ -40,13 +40,15 @@ class H5DataSet(Dataset):
     def __init__(self, data, raw_uint8=False):
         self._data = data
         self._num_samples = data["obss"].shape[0]
-        self._raw_uint8 = bool(raw_uint8)
+        # the raw path uploads the stored bytes; it is taken only when the file really stores uint8 (the reference's
+        # torch.Tensor(x) / 255 accepts any dtype, a blind uint8 cast would wrap or truncate other storage types)
+        self._raw_uint8 = bool(raw_uint8) and np.dtype(data["obss"].dtype) == np.uint8
 
     def __getitem__(self, index):
         res = {}
         for key in self._data.keys():
             if key == "obss" and self._raw_uint8:
-                res["obss_u8"] = torch.from_numpy(np.ascontiguousarray(self._data[key][index], dtype=np.uint8))
+                res["obss_u8"] = torch.from_numpy(np.ascontiguousarray(self._data[key][index]))
             elif key == "obss":
                 res[key] = torch.Tensor(self._data[key][index]).permute(2, 0, 1) / 255.0
             elif key == "labels":

@@ -1,5 +1,5 @@
-"""One rank of the 2-GPU data-parallel parity test (tests/test_gpu_multi.py).  Started as a fresh process per GPU with RANK /
-WORLD_SIZE / MASTER_* in the environment; runs one SLATE.update() on its slice of a fixed batch with injected noise and writes the
+"""One rank of the data-parallel parity test (tests/test_gpu_multi.py).  Started as a fresh process per rank with RANK /
+WORLD_SIZE / MASTER_* in the environment (one GPU per rank over RCCL, or with OCRL_DP_ONE_GPU=1 every rank on cuda:0 over gloo); runs one SLATE.update() on its slice of a fixed batch with injected noise and writes the
 post-all-reduce gradients, the post-step weights and the reported norm to <out>/rank<r>.pt."""
 import os
 import sys
@@ -34,10 +34,15 @@ def run_update(cfg, P, obs, noise, device):
 def main():
     out = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
+    one_gpu = os.environ.get("OCRL_DP_ONE_GPU", "") == "1"      # both ranks on cuda:0, gradients reduced over gloo (RCCL refuses two ranks per device)
+    local = 0 if one_gpu else rank
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     import torch.distributed as dist
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     cfg, P, obs, noise = batch()
     per = B_GLOBAL // world
     sl = slice(rank * per, (rank + 1) * per)

@@ -7,6 +7,9 @@ reference modules from /root/reference exactly as make_golden.py does); writes d
                          _gen_imgs tokens + image + get_loss(with_mse=True)['mse'] (slate_module.py:163-179,234-237)
   slate_masks_bcdec.npz  use_bcdec get_loss(obs, masks): mse and the reported ARI (slate_module.py:207-225, utils/tools.py:309-320), plus the
                          label maps the ARI was computed from
+  slate_sa128_eval.npz   config SA = BASELINE config 2 (use_bcdec, 128x128, 6 slots, 3 iterations), B=1: one reference update() (mse, norm,
+                         per-parameter checksums) + the next step's forward (slots, attention, broadcast-decoder reconstruction) and
+                         gradient checksums (ocrs/common/models.py:110-141, slate_module.py:218-225)
   slate_init_stats.npz   per-tensor statistics of the reference constructors' initialisation (ocrs/common/networks.py:6-74,
                          slot_attn.py:133-136, transformer.py:53-58,193-198) at the 64x64 configuration
 
@@ -157,10 +160,91 @@ def run_init_stats(SLATE):
     print("[init] wrote slate_init_stats.npz for", len(names), "tensors")
 
 
+def run_sa128(SLATE):
+    """BASELINE config 2 at its real size: the reference's update() with use_bcdec=True, then forward + backward of the next step"""
+    from oracle import slate_oracle as O
+    cfg = O.default_cfg(obs_size=128, num_slots=6, num_iterations=3, use_bcdec=True)
+    B, seed = 1, 19
+    model, P = build(SLATE, cfg)
+    mod = model._module
+    S, K = cfg.obs_size, cfg.num_slots
+    obs = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(seed + 1000))
+    trainer = O.OracleTrainer(cfg, P)
+    rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-12)).item()
+    out = {"B": B, "seed": seed}
+    step = 0
+    noise = O.make_noise(cfg, B, seed + step)
+    torch.manual_seed(seed + step)              # update() draws the dVAE's two Gumbel fields (dead work in this mode) and then the slot noise
+    m_ref = model.update(obs, None, step)
+    res = trainer.update(obs, noise, step, None)
+    assert rel(res["loss"].detach(), m_ref["loss"].detach()) < 2e-5 and abs(float(res["norm"]) - float(m_ref["norm"])) / float(m_ref["norm"]) < 2e-5
+    out["s0.loss"] = np.float64(m_ref["loss"].item())
+    out["s0.mse"] = np.float64(m_ref["mse"].item())
+    out["s0.norm"] = np.float64(float(m_ref["norm"]))
+    for k in ("lr_dvae", "lr_enc", "lr_dec"):
+        out[f"s0.{k}"] = np.float64(m_ref[k].item())
+    names, sums, worst = [], [], 0.0
+    for n, p in mod.named_parameters():
+        if not p.requires_grad:
+            continue
+        worst = max(worst, rel(trainer.P[n].detach(), p.detach()))
+        names.append(n)
+        sums.append(MG.summarize(p))
+        out["paramhead." + n] = p.detach().flatten()[:16].numpy().copy()
+    assert worst < 5e-5, worst
+    out["param_names"] = np.array(names)
+    out["param_sums"] = np.stack(sums)
+    print(f"[sa128] update(): mse {out['s0.mse']:.6f} norm {out['s0.norm']:.6f}; oracle vs reference parameters after the step {worst:.2e}")
+    # ---- next step: forward intermediates and raw gradients
+    step = 1
+    noise = O.make_noise(cfg, B, seed + step)
+    model._opt.zero_grad()
+    mod.update_tau(step)
+    torch.manual_seed(seed + step)
+    _ = torch.empty_like(noise["z"]).exponential_()
+    _ = torch.empty_like(noise["z"]).exponential_()
+    with torch.no_grad():
+        got = mod._get_slots(obs, with_attns=True)
+        slots, attns = got[0], got[1]
+        recon = mod._dec(slots)
+    torch.manual_seed(seed + step)
+    m = mod.get_loss(obs, None)
+    m["loss"].backward()
+    tr2 = O.OracleTrainer(cfg, {n: trainer.P[n].detach() for n in trainer.P})
+    r2 = tr2.loss_and_grads(obs, noise, step, None)
+    assert rel(r2["loss"].detach(), m["loss"].detach()) < 2e-5
+    assert rel(r2["slots"].detach(), slots.detach()) < 2e-5 and rel(r2["attn"].detach(), attns.detach()) < 2e-5
+    assert rel(r2["recon_bc"].detach(), recon.detach()) < 2e-5
+    gmax = max(p.grad.abs().max().item() for p in mod.parameters() if p.requires_grad and p.grad is not None)
+    gw, gnames, gsums = 0.0, [], []
+    for n, p in mod.named_parameters():
+        if not p.requires_grad or p.grad is None:
+            assert (not p.requires_grad) or tr2.P[n].grad is None or float(tr2.P[n].grad.abs().max()) == 0.0, n
+            continue
+        e_ = ((tr2.P[n].grad.double() - p.grad.double()).abs().max() / max(p.grad.double().abs().max().item(), 1e-6 * gmax)).item()
+        gw = max(gw, e_)
+        gnames.append(n)
+        gsums.append(MG.summarize(p.grad))
+    out["grad_oracle_vs_reference"] = np.float64(gw)
+    print(f"[sa128] forward/backward at step 1: oracle vs reference gradients (max-norm per tensor) {gw:.2e} over {len(gnames)} tensors")
+    out["fwd.mse"] = np.float64(m["mse"].item())
+    out["fwd.slots"] = slots.detach().numpy().copy()
+    out["fwd.attn_sums"] = attns.detach().sum(1).numpy().copy()
+    out["fwd.attn_head"] = attns.detach()[:, :64].numpy().copy()
+    out["fwd.recon_sums"] = MG.summarize(recon)
+    out["fwd.recon_head"] = recon.detach()[:, :, :4, :8].numpy().copy()
+    out["grad_names"] = np.array(gnames)
+    out["grad_sums"] = np.stack(gsums)
+    np.savez_compressed(os.path.join(HERE, "slate_sa128_eval.npz"), **out)
+    print("[sa128] wrote slate_sa128_eval.npz")
+
+
 def main():
     from oracle import slate_oracle as O
     SLATE = MG.import_reference()
     torch.set_num_threads(8)
+    if "--only-sa128" in sys.argv:
+        return run_sa128(SLATE)
     if "--only-a128" not in sys.argv:
         run_surface(SLATE)
         run_masks_bcdec(SLATE)
@@ -171,6 +255,7 @@ def main():
     # _dvae._decoder.0.m.weight 1.1e-2, _tfdec.blocks.3.ffn.0.weight 7e-3).  Loss terms, norm and the parameters after update() agree to
     # 1e-7; the GPU test therefore pins those tightly and grades gradients against an fp64 run of the oracle instead.
     MG.run_case("a128_eval", a128, B=1, seed=9, train_dropout=False, n_steps=1, SLATE=SLATE, full=False, grad_tol=5e-2)
+    run_sa128(SLATE)
 
 
 if __name__ == "__main__":

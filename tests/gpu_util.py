@@ -142,6 +142,17 @@ class ForcedRelu:
         assert self.i == len(self.masks), (self.i, len(self.masks))
 
 
+def assert_knife_edge(fr, tag=""):
+    """Mask matching may excuse rounding ties and nothing else: the ReLU decisions imposed on the fp64 run may differ from fp64's own
+    only in a handful of units whose pre-activation lies inside fp32 rounding noise of zero.  A kernel that takes a wrong decision at a
+    non-negligible pre-activation, or many of them, fails here instead of being carried into the oracle."""
+    limit = max(4, int(1e-6 * fr.units))
+    assert fr.flips <= limit, f"{tag}: {fr.flips} of {fr.units} ReLU decisions of the HIP forward differ from the fp64 oracle's own (limit {limit})"
+    if fr.flips:
+        worst = max(fr.min_flipped)
+        assert worst <= 1e-5, f"{tag}: a flipped ReLU decision at |pre-activation| = {worst:.2e} (> 1e-5) is not a rounding tie"
+
+
 def mask_matched_fp64_grads(cfg, P, obs, noise, step, masks, drop_masks=None):
     """fp64 run of the oracle with the given ReLU decisions; returns (trainer with .P[name].grad, ForcedRelu stats)"""
     from oracle import slate_oracle as O

@@ -23,6 +23,26 @@ def test_library_exports_every_declared_symbol():
     assert L.ocrl_abi_version() == 4
 
 
+def test_config_struct_matches_the_header():
+    """the binding's SlateConfig and INTEGRATION.md's Cfg snippet carry every field of ocrl_slate_config, in order, and the library
+    reports the same size (a host that copies a struct one field short would hand ocrl_slate_create 4 bytes of garbage)"""
+    from ocrl_amd import _lib
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "ocrl_hip.h")).read()
+    body = re.search(r"typedef struct ocrl_slate_config \{(.*?)\} ocrl_slate_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields += [f.strip() for f in decl.split(None, 1)[1].split(",")]
+    assert [n for n, _ in _lib.SlateConfig._fields_] == fields
+    assert L.ocrl_slate_config_size() == ctypes.sizeof(_lib.SlateConfig) == 4 * len(fields)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    snippet = doc[doc.index("class Cfg(ctypes.Structure):"):doc.index("h = ctypes.c_void_p()")]
+    assert re.findall(r'"([a-z_]+)"', snippet) == fields
+
+
 @pytest.mark.parametrize("over", [dict(obs_size=64), dict(obs_size=128, num_slots=6), dict(obs_size=16, vocab_size=256, num_dec_blocks=2),
                                   dict(obs_size=32, num_slots=6, use_bcdec=True)])
 def test_param_table_matches_reference_inventory(over):

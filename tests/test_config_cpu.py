@@ -137,3 +137,15 @@ def test_pooling_module_mirrors_reference_state_dict():
     assert tuple(m1.state_dict()["_trans._linear.weight"].shape) == (128, 128)
     m2 = Transformer_Module(192, 6, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", use_mlp2=True))
     assert [k for k in m2.state_dict() if k.startswith("mlp.")] == ["mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias"]
+
+
+def test_multi_head_slot_attention_is_refused():
+    """ocr.slotattr.num_slot_heads != 1 (ocrs/common/slot_attn.py:28,54-92) is not built on the HIP backend: constructing raises instead of
+    silently running the single-head kernels"""
+    from ocrl_amd import ocrs
+    c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2", "ocr.slotattr.num_slot_heads=2"])
+    with pytest.raises(NotImplementedError, match="num_slot_heads"):
+        ocrs.SLATE(c.ocr, c.dataset)
+    c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2"])
+    assert c.ocr.slotattr.num_slot_heads == 1
+    ocrs.SLATE(c.ocr, c.dataset)           # the shipped configuration constructs (CPU container tensors; .to(cuda) is needed to run)

@@ -1,0 +1,155 @@
+"""Correctness at the BENCHED batch size (B = 128 per GPU), configs A (128x128 / 6 slots) and Z (256x256 / 16 slots) — the shapes
+bench.py times.  The oracle cannot run 128 images in seconds, so these are size-independent properties of the step
+(ocrs/slate/slate_module.py:198-241: every loss is a sum over images / B and no operator mixes images):
+
+  * replicated image: 128 copies of one image with identical injected noise.  Every per-image quantity (tokens, slots, attention,
+    reconstruction) of image 0 and of image 127 equals that of a B = 1 engine on the same image, the loss terms (sum / B of 128 equal
+    terms) equal the B = 1 terms, and the gradient (sum over images / B) equals the B = 1 gradient.  This exercises what only exists
+    at the benched grid size: the 33 GiB (85 GiB at Z) workspace, the 2^29- (2^31-) element [B*T, V] buffers, 8 streaming workgroups per
+    image, the split-K counts and the XCD-aware block orders of full launches;
+  * two runs of two training steps (train mode, device RNG, clip + Adam) are bitwise identical: with hand-written kernels and no GPU
+    sanitizer this is the race detector (tests/test_gpu_determinism.py) — at a grid where > 256 workgroups are resident.
+
+The gradient of the replicated batch is graded per tensor against the B = 1 gradient at GRAD_TOL (tests/test_gpu_slate.py); the ReLU
+decisions of image 0 in both runs are compared first (the slot-attention partial sums are grouped differently at B = 1 and B = 128, so a
+pre-activation downstream of the slots that sits inside rounding noise of zero could fall differently): the flips must be knife-edge
+only, and the gradient is graded tightly when there are none."""
+import pytest
+import torch
+
+from oracle import slate_oracle as O          # closed-form weights and the schedules only
+from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, relerr
+from tests.test_gpu_slate import GRAD_TOL
+
+pytestmark = pytest.mark.gpu
+B = 128
+
+CONFIGS = [
+    ("config A 128x128/6 slots B=128", dict(obs_size=128, num_slots=6, num_iterations=3)),
+    ("config Z 256x256/16 slots B=128", dict(obs_size=256, num_slots=16, num_iterations=3)),
+]
+
+
+def _free_gib():
+    free, _ = torch.cuda.mem_get_info()
+    return free / 2 ** 30
+
+
+def _need(cfg, gib):
+    if _free_gib() < gib:
+        pytest.skip(f"needs {gib} GiB of free HBM")
+
+
+def _one_image_noise(cfg, seed):
+    E = cfg.obs_size // 4
+    T, V, K, D = E * E, cfg.vocab_size, cfg.num_slots, cfg.slot_size
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return dict(z=torch.empty(1, T, V, device="cuda").exponential_(generator=g), z_hard=torch.empty(1, T, V, device="cuda").exponential_(generator=g),
+                slots=torch.randn(1, K, D, device="cuda", generator=g))
+
+
+def _masks_image0(eng, cfg, nb):
+    """ReLU decisions of image 0 (hip_relu_masks reads whole-batch tensors; only the first image is kept)"""
+    return [m[:1].clone() for m in hip_relu_masks(eng, cfg, nb)]
+
+
+@pytest.mark.parametrize("tag,over", CONFIGS)
+def test_replicated_image_equals_single_image_engine(tag, over):
+    from ocrl_amd.engine import SlateEngine
+    cfg = O.default_cfg(**over)
+    _need(cfg, 120 if cfg.obs_size == 256 else 50)
+    S, E = cfg.obs_size, cfg.obs_size // 4
+    T, N, V, K, D = E * E, S * S, cfg.vocab_size, cfg.num_slots, cfg.slot_size
+    P = O.formula_params(cfg)
+    step = 25
+    tau, _ = O.schedules(cfg, step)
+    obs1 = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(5)).cuda()
+    n1 = _one_image_noise(cfg, 6)
+
+    def run(nb):
+        eng = SlateEngine(dims_from_cfg(cfg), max_batch=nb)
+        load_params(eng, P)
+        obs = obs1.expand(nb, -1, -1, -1).contiguous()
+        noise = {k: v.expand(nb, -1, -1).contiguous() for k, v in n1.items()}
+        eng.forward(obs, tau, train=False, seed=1, noise=noise)
+        torch.cuda.synchronize()
+        out = dict(m=eng.metrics.cpu().clone().double(), tokens=eng.tensor("tokens", (nb, T), torch.int32).cpu().clone(),
+                   slots=eng.tensor("slots", (nb, K, D)).cpu().clone(), attn=eng.tensor("attn", (nb, N, K)).cpu().clone(),
+                   recon=eng.tensor("recon", (nb, S, S, 4))[..., :3].cpu().clone(), dec_out=eng.tensor("dec_out", (nb, T, cfg.d_model)).cpu().clone())
+        out["masks"] = _masks_image0(eng, cfg, nb)
+        eng.backward()
+        torch.cuda.synchronize()
+        out["g"] = eng.flat_g.cpu().clone()
+        out["params"] = eng.params
+        out["view"] = eng.view
+        del noise, obs
+        return out
+
+    one = run(1)
+    rep = run(B)
+    assert torch.isfinite(rep["m"][:3]).all() and torch.isfinite(rep["g"]).all()
+    # loss terms: sum of 128 equal terms / 128
+    for i, k in enumerate(("dvae_mse", "cross_entropy", "loss")):
+        e = abs(rep["m"][i].item() - one["m"][i].item()) / abs(one["m"][i].item())
+        assert e < 1e-6, (k, rep["m"][i].item(), one["m"][i].item())
+    # per-image quantities of the first and the last image
+    worst = {}
+    for b in (0, B - 1):
+        assert torch.equal(rep["tokens"][b], one["tokens"][0]), f"tokens of image {b}"
+        for k in ("slots", "attn", "recon", "dec_out"):
+            worst[k] = max(worst.get(k, 0.0), relerr(rep[k][b], one[k][0]))
+    same = all(torch.equal(rep[k][0], rep[k][B - 1]) for k in ("slots", "attn", "recon", "dec_out"))
+    log(f"[{tag}] replicated image vs B=1 engine: " + " ".join(f"{k}={v:.2e}" for k, v in worst.items()) + f"; image 0 == image {B - 1} bitwise: {same}")
+    for k, v in worst.items():
+        assert v < 1e-6, (k, v)
+    # every image of the batch, against image 0 (cheap: on the tensors already on the host)
+    for k in ("slots", "recon"):
+        spread = (rep[k] - rep[k][:1]).abs().max().item() / rep[k][0].abs().max().item()
+        assert spread < 1e-6, (k, spread)
+    # ReLU decisions of image 0 in both runs
+    flips, units = 0, 0
+    for a, b_ in zip(one["masks"], rep["masks"]):
+        flips += int((a != b_).sum())
+        units += a.numel()
+    assert flips <= 4, (flips, units)
+    # gradient: sum over 128 equal images / 128 == the single image's gradient
+    gmax = one["g"].abs().max().item()
+    rows = sorted(((relerr(rep["view"](rep["g"], p), one["view"](one["g"], p), floor=grad_floor(p.name, gmax)), p.name) for p in one["params"]), reverse=True)
+    tol = GRAD_TOL if flips == 0 else 1e-3
+    log(f"[{tag}] gradient of the replicated batch vs B=1: worst {rows[0][0]:.2e} ({rows[0][1]}); {flips} of {units} ReLU decisions of image 0 differ; "
+        f"tolerance {tol:.0e}; top: " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:4]))
+    assert rows[0][0] < tol, rows[:5]
+
+
+@pytest.mark.parametrize("tag,over", CONFIGS)
+def test_two_runs_bitwise_identical_at_bench_batch(tag, over):
+    from ocrl_amd.engine import SlateEngine
+    from ocrl_amd.utils.data import random_sprite_scenes, scenes_to_obs
+    cfg = O.default_cfg(**over)
+    _need(cfg, 120 if cfg.obs_size == 256 else 50)
+    P = O.formula_params(cfg)
+    obs = scenes_to_obs(random_sprite_scenes(B, cfg.obs_size, seed=3)).cuda()
+    runs = []
+    for _ in range(2):
+        eng = SlateEngine(dims_from_cfg(cfg), max_batch=B)
+        load_params(eng, P)
+        trace = []
+        for step in range(2):
+            tau, lrs = O.schedules(cfg, step)
+            eng.forward(obs, tau, train=True, seed=900 + step)          # Gumbel / slot noise / 21 dropout sites from the device RNG
+            eng.backward()
+            torch.cuda.synchronize()
+            g = eng.flat_g.cpu().clone()
+            eng.clip_adam(lrs, cfg.clip)
+            torch.cuda.synchronize()
+            trace.append((eng.metrics.cpu().clone(), g))
+        runs.append((trace, eng.flat_p.cpu().clone(), eng.flat_m.cpu().clone(), eng.flat_v.cpu().clone()))
+        del eng
+        torch.cuda.empty_cache()
+    (ta, pa, ma, va), (tb, pb, mb, vb) = runs
+    for step, ((m1, g1), (m2, g2)) in enumerate(zip(ta, tb)):
+        assert torch.isfinite(g1).all() and torch.isfinite(m1[:4]).all()
+        assert torch.equal(m1[:4], m2[:4]), (tag, step, m1, m2)
+        assert torch.equal(g1, g2), (tag, step, int((g1 != g2).sum()), float((g1 - g2).abs().max()))
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    log(f"[{tag}] two runs of two training steps (device RNG, train mode): bitwise identical; losses {[float(t[0][2]) for t in ta]}")

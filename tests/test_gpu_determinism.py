@@ -105,3 +105,50 @@ def test_device_rng_quality():
     assert abs(corr(a[:-1], a[1:])) < 4e-3 and abs(corr(a[:-4], a[4:])) < 4e-3 and abs(corr(a[:-64], a[64:])) < 4e-3      # serial
     assert abs(corr(a, b)) < 4e-3 and abs(corr(a, c)) < 4e-3                                                                   # site / seed
     assert not torch.equal(a, b) and not torch.equal(a, c)
+
+
+def _mix32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def _rng_key(seed, site, hi=0):
+    """csrc/common.h rng_key"""
+    return _mix32((seed & 0xFFFFFFFF) ^ ((site * 0x9E3779B9) & 0xFFFFFFFF)) ^ _mix32(((seed >> 32) + 0x85EBCA6B * (hi + 1)) & 0xFFFFFFFF)
+
+
+def test_device_rng_streams_are_not_translates():
+    """Two (seed, site) streams must not be XOR-translates of each other.  With the key only xor-ed into the counter, stream B at group i
+    equalled stream A at group i ^ (kA ^ kB): a whole dropout / Gumbel field re-used as a block permutation.  The test picks two seeds whose
+    keys differ only in the low 19 bits (found with the host restatement of rng_key), so the translate, if it existed, would map the
+    dumped 2^19 groups onto themselves, and requires the translated masks to agree at chance level only."""
+    from ocrl_amd.engine import SlateEngine
+    site, nbits = 17, 19
+    seen, pair = {}, None
+    for s in range(1, 1 << 14):
+        k = _rng_key(s, site)
+        if (k >> nbits) in seen:
+            pair = (seen[k >> nbits], s)
+            break
+        seen[k >> nbits] = s
+    assert pair is not None
+    d = _rng_key(pair[0], site) ^ _rng_key(pair[1], site)
+    assert 0 < d < (1 << nbits)
+    cfg = O.default_cfg(obs_size=16, vocab_size=256, num_slots=3, num_iterations=1, num_dec_blocks=1)
+    eng = SlateEngine(dims_from_cfg(cfg), max_batch=1)
+    load_params(eng, O.formula_params(cfg))
+    obs = torch.rand(1, 3, 16, 16, device="cuda")
+    n = 4 << nbits
+
+    def groups(seed):
+        eng.forward(obs, 1.0, train=True, seed=seed)
+        return eng.dropout_mask(site, (n,)).cpu().view(-1, 4)
+
+    a, b = groups(pair[0]), groups(pair[1])
+    idx = torch.arange(1 << nbits) ^ d
+    agree = (a[idx] == b).all(1).double().mean().item()        # a whole group of four keep decisions equal
+    chance = (0.9 * 0.9 + 0.1 * 0.1) ** 4
+    assert abs(agree - chance) < 0.01, (agree, chance, d)

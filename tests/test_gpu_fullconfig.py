@@ -23,7 +23,7 @@ import pytest
 import torch
 
 from oracle import slate_oracle as O
-from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, mask_matched_fp64_grads, relerr
+from tests.gpu_util import assert_knife_edge, dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, mask_matched_fp64_grads, relerr
 from tests.test_gpu_slate import GRAD_TOL, compare_forward, dev_noise
 
 pytestmark = pytest.mark.gpu
@@ -137,8 +137,9 @@ def replay_reference_fixture(tag, cfg, fx):
              recon_sums=float(np.max(np.abs(_summ(recon) - fx["fwd.recon_sums"])[1:] / np.abs(fx["fwd.recon_sums"])[1:])))
     log(f"[{tag}] forward at step 1 vs the reference: " + " ".join(f"{k}={v:.2e}" for k, v in e.items()))
     assert e["slots"] < 1e-4 and e["attn_head"] < 1e-4 and e["attn_sums"] < 1e-4 and e["recon_head"] < 1e-4 and e["recon_sums"] < 1e-5, e
-    # gradient checksums: the L2 norm of every tensor; tolerance = what separates the reference from the fp32 oracle on this fixture
-    tol = max(2e-4, 3.0 * float(fx["grad_oracle_vs_reference"])) if "grad_oracle_vs_reference" in fx else 2e-4
+    # gradient checksums: the L2 norm of every tensor.  A ReLU coin toss moves a tensor's L2 norm far less than its max-norm
+    # (fx["grad_oracle_vs_reference"]): measured 3.7e-6 at 128x128 and 1.2e-5 at 64x64, so the tolerance is 10x that, not the max-norm gap
+    tol = 2e-4
     gmax = max(float(np.sqrt(s[2])) for s in fx["grad_sums"])
     worst = 0.0
     for n, ref in zip([str(x) for x in fx["grad_names"]], fx["grad_sums"]):
@@ -192,6 +193,7 @@ def test_full_config_against_oracle(tag, over, B):
     grade_gradients(tag, eng, t32, t64)          # logged, not asserted: with each side's own ReLU decisions the comparison is a coin toss (see above)
     # with the ReLU decisions of the HIP forward held fixed in the fp64 run: tight, per tensor
     t64m, fr = mask_matched_fp64_grads(cfg, P, obs, noise, step, hip_relu_masks(eng, cfg, B))
+    assert_knife_edge(fr, tag)
     gmax = max(t64m.P[p.name].grad.abs().max().item() for p in eng.params)
     rows = sorted(((relerr(eng.view(eng.flat_g, p), t64m.P[p.name].grad.reshape(p.shape), floor=grad_floor(p.name, gmax)), p.name) for p in eng.params), reverse=True)
     log(f"[{tag}] gradients vs mask-matched fp64 oracle: worst {rows[0][0]:.2e} ({fr.flips} of {fr.units} ReLU decisions of the HIP forward differ from "

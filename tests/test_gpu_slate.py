@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, mask_matched_fp64_grads, relerr
+from tests.gpu_util import assert_knife_edge, dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, mask_matched_fp64_grads, relerr
 from oracle import slate_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -100,6 +100,7 @@ def compare_grads(tag, eng, trainer, cfg=None, P=None, obs=None, noise=None, ste
         return worst32, rows32
     B = obs.shape[0]
     t64, fr = mask_matched_fp64_grads(cfg, P, obs, noise, step, hip_relu_masks(eng, cfg, B), drop_masks)
+    assert_knife_edge(fr, tag)
     worst, rows = 0.0, []
     for p in eng.params:
         ref = t64.P[p.name].grad

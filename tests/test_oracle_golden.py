@@ -97,6 +97,28 @@ def test_bcdec_matches_reference(golden_dir):
         np.testing.assert_allclose(_summ(tr.P[n])[1:], ref[1:], rtol=2e-5, err_msg=n)
 
 
+def test_sa128_real_config_matches_reference(golden_dir):
+    """BASELINE config 2 at its real size (use_bcdec, 128x128 / 6 slots / 3 iterations), B=1: the reference's update() and the next
+    step's forward / gradient checksums (tests/golden/make_golden_extras.py run_sa128)"""
+    fx = np.load(os.path.join(golden_dir, "slate_sa128_eval.npz"))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    cfg = O.default_cfg(obs_size=128, num_slots=6, num_iterations=3, use_bcdec=True)
+    B, seed = int(fx["B"]), int(fx["seed"])
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(seed + 1000))
+    tr = O.OracleTrainer(cfg, O.formula_params(cfg))
+    res = tr.update(obs, O.make_noise(cfg, B, seed), 0, None)
+    assert float(res["loss"]) == pytest.approx(float(fx["s0.loss"]), rel=2e-5)
+    assert float(res["norm"]) == pytest.approx(float(fx["s0.norm"]), rel=2e-5)
+    for n, ref in zip([str(x) for x in fx["param_names"]], fx["param_sums"]):
+        np.testing.assert_allclose(_summ(tr.P[n])[1:], ref[1:], rtol=2e-5, err_msg=n)
+    tr2 = O.OracleTrainer(cfg, {n: p.detach() for n, p in tr.P.items()})
+    r2 = tr2.loss_and_grads(obs, O.make_noise(cfg, B, seed + 1), 1, None)
+    assert float(r2["loss"]) == pytest.approx(float(fx["fwd.mse"]), rel=2e-5)
+    np.testing.assert_allclose(r2["slots"].detach().numpy(), fx["fwd.slots"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(r2["attn"].detach().sum(1).numpy(), fx["fwd.attn_sums"], rtol=1e-4)
+    np.testing.assert_allclose(_summ(r2["recon_bc"])[1:], fx["fwd.recon_sums"][1:], rtol=2e-5)
+
+
 def test_param_counts_match_survey():
     """S=64: 5 388 099 trainable; S=128: 5 535 555; bcdec adds 515 460."""
     def count(cfg):
