@@ -109,7 +109,7 @@ int rowdot_bias64_launch(const float* g, const float* act, const float* bias, lo
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st);
 int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, const float* pe, float* out, int B, int T, int d, float p,
                      unsigned long long seed, hipStream_t st);
-size_t embed_bwd_ws_floats(int V, int d);
+size_t embed_bwd_ws_floats(long long BT, int V, int d);
 int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, int V, int d, float p, unsigned long long seed, float* ws,
                      size_t ws_floats, hipStream_t st);
 int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st);
@@ -182,6 +182,9 @@ struct SlotAttnArgs {
     // one-workgroup-per-image kernels
     float* xchg = nullptr;
     float* parts = nullptr;
+    // forward only: 0 = whole chain; 1 = the preparation launch alone (slots0 -> slots / folded query of iteration 0 in xchg; needs the
+    // weights and slots0 but not x, so a caller can issue it long before the features exist); 2 = the chain without that launch
+    int phase = 0;
 };
 size_t sa_xchg_floats_host(int K, int D);      // per image
 size_t sa_parts_floats_host(int B, int K);

@@ -111,6 +111,9 @@ SlateModel::~SlateModel() {
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_tokens_) (void)hipEventDestroy(ev_tokens_);
     if (side_) (void)hipStreamDestroy(side_);
+    for (hipEvent_t e : ev_dw_) if (e) (void)hipEventDestroy(e);
+    if (ev_join2_) (void)hipEventDestroy(ev_join2_);
+    if (side2_) (void)hipStreamDestroy(side2_);
 }
 
 float* SlateModel::P(const std::string& n) const { return p_ + params_[index_.at(n)].offset; }
@@ -138,7 +141,7 @@ void SlateModel::layout_workspace(bool commit) {
         size_t cs = (size_t)N * C * 8 + (size_t)T * d * 8 + (1 << 20);   // column-sum partials (pos map / pe)
         if (cs > need) need = cs;
         if (cfg.use_bcdec && bc_layer1_bwd_ws_floats((int)(B * K), S) > need) need = bc_layer1_bwd_ws_floats((int)(B * K), S);
-        const size_t ca = cross_attn_bwd_ws_floats((int)B, T, K, d, NH), eb = embed_bwd_ws_floats(V, d);
+        const size_t ca = cross_attn_bwd_ws_floats((int)B, T, K, d, NH), eb = embed_bwd_ws_floats((long long)B * T, V, d);
         if (ca > need) need = ca;
         if (eb > need) need = eb;
         scratch_floats_ = need + (1 << 20);
@@ -168,7 +171,7 @@ void SlateModel::layout_workspace(bool commit) {
         cw_bwd_[i] = i == 0 ? nullptr : carve(nullptr, (size_t)25 * 64 * 64);
     }
     gslots_ = carve(nullptr, BK * D); gslots0_ = carve(nullptr, BK * D);
-    gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64);
+    gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64); gC_ = cfg.use_bcdec ? gA_ : carve(nullptr, BN * 64);
     gmap_ = carve(nullptr, (size_t)N * C);
     if (cfg.use_bcdec) {
         const size_t BKN = BK * (size_t)N;
@@ -221,6 +224,14 @@ void SlateModel::layout_workspace(bool commit) {
     pred_ = carve("pred", BT * V);
     gx_ = carve(nullptr, BT * d); gbr_ = carve(nullptr, BT * d); gt1_ = carve(nullptr, BT * d); gt2_ = carve(nullptr, BT * d);
     gt3_ = carve(nullptr, BT * d); gf1_ = carve(nullptr, BT * 4 * d); gqkv_ = carve(nullptr, BT * 3 * d);
+    bg_.resize(NB);
+    for (int b = 0; b < NB; ++b) {
+        BlkG& q = bg_[b];
+        if (b == 0) { q.gbr[0] = gbr_; q.gf1 = gf1_; q.gt2 = gt2_; q.gqkv = gqkv_; }
+        else { q.gbr[0] = carve(nullptr, BT * d); q.gf1 = carve(nullptr, BT * 4 * d); q.gt2 = carve(nullptr, BT * d); q.gqkv = carve(nullptr, BT * 3 * d); }
+        q.gbr[1] = carve(nullptr, BT * d); q.gbr[2] = carve(nullptr, BT * d);
+    }
+    scratch3_ = carve(nullptr, scratch_floats_);
     gmem_ = carve(nullptr, BK * d); gck_ = carve(nullptr, BK * d); gcv_ = carve(nullptr, BK * d);
     gdA_ = carve(nullptr, BN * 64); gdB_ = carve(nullptr, BN * 64);
     }
@@ -260,6 +271,16 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
             OCRL_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
             OCRL_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
             OCRL_HIP(hipEventCreateWithFlags(&ev_tokens_, hipEventDisableTiming));
+            // OCRL_DW_SIDE (default 2): the weight-gradient products of the transformer decoder leave the main stream -- nothing later in
+            // the step reads them, while the input-gradient chain they would otherwise interrupt is the step's critical path.
+            //   1 = on the dVAE side stream (behind the dVAE backward), 2 = on a stream of their own, 0 = on the main stream (round 2)
+            const char* w = getenv("OCRL_DW_SIDE");
+            dw_mode_ = (overlap_mode_ >= 3 && !cfg.use_bcdec) ? (w ? atoi(w) : 2) : 0;
+            if (dw_mode_) {
+                for (hipEvent_t& ev : ev_dw_) OCRL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                OCRL_HIP(hipEventCreateWithFlags(&ev_join2_, hipEventDisableTiming));
+                if (dw_mode_ == 2) OCRL_HIP(hipStreamCreateWithFlags(&side2_, hipStreamNonBlocking));
+            }
         }
     }
     // static tables
@@ -412,6 +433,17 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae)
         std::swap(scratch_, scratch2_);
         return rc;
     };
+    // slot initialisation and the preparation launch of the slot-attention chain (LayerNorm, q, folded query of iteration 0) need the
+    // weights and the noise only: issued first, they run on an otherwise idle machine.  After the fork their whole-CU-LDS workgroups
+    // queue behind the Gumbel head's 32 768 small workgroups on the side stream (measured: 1.46 ms instead of 60 us, on the critical
+    // path of the decoder)
+    RC(slot_init_launch(P("_slotattn.slot_mu"), P("_slotattn.slot_log_sigma"), in.noise_slots, slots0_, B * K, D, in.seed, st));
+    SlotAttnArgs a;
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
+    a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
+    a.xchg = sa_xchg_; a.parts = sa_parts_;
+    a.phase = 1;
+    RC(slot_attn_launch(a, 0, st));
     if (fork_dvae == 2) RC(fork_here());
     RC(nchw_to_nhwc8_launch(in.obs, obs8_, B, cfg.obs_channels, S, S, st));
     RC(conv_layer_fwd(obs8_, cw_fwd_[0], P("_enc._encoder.0.m.bias"), e1_, B, S, S, 5, 8, 1, nullptr, nullptr, st));
@@ -422,12 +454,8 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae)
     RC(layernorm_fwd_launch(e4_, P("_slotattn.layer_norm.weight"), P("_slotattn.layer_norm.bias"), ln0_, ln0_mean_, ln0_rstd_, BN, C, st));
     RC(lin_fwd(ln0_, C, P("_slotattn.mlp.0.weight"), P("_slotattn.mlp.0.bias"), h1_, C, BN, C, C, 1, nullptr, 0, 0.f, 0, st));
     RC(lin_fwd(h1_, C, P("_slotattn.mlp.2.weight"), P("_slotattn.mlp.2.bias"), x_, C, BN, C, C, 0, nullptr, 0, 0.f, 0, st));
-    RC(slot_init_launch(P("_slotattn.slot_mu"), P("_slotattn.slot_log_sigma"), in.noise_slots, slots0_, B * K, D, in.seed, st));
-    SlotAttnArgs a;
-    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
-    a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
-    a.xchg = sa_xchg_; a.parts = sa_parts_;
     if (fork_dvae == 1) RC(fork_here());
+    a.phase = 2;
     RC(slot_attn_launch(a, 0, st));
     return 0;
 }
@@ -664,9 +692,30 @@ int SlateModel::bwd_decoder(hipStream_t st) {
     const long long BT = (long long)B * T, BK = (long long)B * K;
     const float p = pdrop_;
     const float scale = 1.0f / sqrtf((float)DH);
+    // Weight-gradient products on a side stream (OCRL_DW_SIDE): `dw_sync` makes the side stream wait for everything the main stream has
+    // enqueued so far, `dw` enqueues one product there (with the side stream's own split-k scratch).  The operands such a product reads
+    // are never rewritten by the main stream during this backward: saved activations, and the per-block gradient temporaries bg_[b].
+    const bool dws = dw_mode_ != 0 && side_ != nullptr;
+    hipStream_t sw = dws ? (dw_mode_ == 2 ? side2_ : side_) : st;
+    float* const sw_scratch = dw_mode_ == 2 ? scratch3_ : scratch2_;
+    auto dw_sync = [&]() -> int {
+        if (!dws) return 0;
+        hipEvent_t ev = ev_dw_[ev_dw_next_++ & 7];
+        OCRL_HIP(hipEventRecord(ev, st));
+        OCRL_HIP(hipStreamWaitEvent(sw, ev, 0));
+        return 0;
+    };
+    auto dw = [&](const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db, long long M, int N_out, int K_in, Xf xf = Xf()) -> int {
+        float* keep = scratch_;
+        if (dws) scratch_ = sw_scratch;
+        const int rc = lin_bwd_w(dy, ld_dy, x, ldx, dW, db, M, N_out, K_in, 1.f, sw, Drop(), xf);
+        scratch_ = keep;
+        return rc;
+    };
     // output head: d loss / d pred = (softmax(pred_) - onehot(tokens)) / B, rebuilt from the logits as both products stage their A tiles
     Xf ce; ce.a_mode = 3; ce.lse = celse_; ce.tok = tokens_; ce.scale = 1.0f / last_.B;
-    RC(lin_bwd_w(pred_, V, lnf_, d, G("_out.weight"), nullptr, BT, V, d, 1.f, st, Drop(), ce));
+    RC(dw_sync());
+    RC(dw(pred_, V, lnf_, d, G("_out.weight"), nullptr, BT, V, d, ce));
     RC(lin_bwd_x(pred_, V, P("_out.weight"), gt1_, d, BT, V, d, nullptr, 0, nullptr, 0, st, Drop(), ce));
     const float* xlast = blk_[NB - 1].x3;
     RC(layernorm_bwd_launch(gt1_, xlast, lnf_mean_, lnf_rstd_, P("_tfdec.layer_norm.weight"), gx_, G("_tfdec.layer_norm.weight"), BT, d, 0, 0,
@@ -674,32 +723,37 @@ int SlateModel::bwd_decoder(hipStream_t st) {
     RC(fill_launch(gmem_, BK * d, 0.f, st));
     for (int b = NB - 1; b >= 0; --b) {
         Blk& k = blk_[b];
+        const BlkG& q = bg_[dws ? b : 0];
         const std::string pre = fmt("_tfdec.blocks.%d.", b);
         const unsigned site = SITE_BLK_BASE + 8 * b;
         const float* xin = (b == 0) ? emb_ : blk_[b - 1].x3;
         // ---- feed forward:  x3 = x2 + drop(W2 relu(W1 ln3 + b1) + b2)
-        // the gradient entering a residual branch is dropout-backward(gx) of the branch's site: applied once into gbr_ and fed to both
-        // the weight-gradient and the input-gradient product (drawing the mask inside the products made each 40-90 % slower)
+        // the gradient entering a residual branch is dropout-backward(gx) of the branch's site: applied once into a buffer of its own and
+        // fed to both the weight-gradient and the input-gradient product (drawing the mask inside the products made each 40-90 % slower).
+        // With the weight gradients on the side stream the copy is also taken when there is no dropout: gx_ itself moves on.
         const float* gd = gx_;
-        auto drop_gx = [&](unsigned s_) -> int {
+        auto drop_gx = [&](unsigned s_, float* into) -> int {
             gd = gx_;
-            if (p > 0.f) { RC(dropout_apply_launch(gx_, gbr_, BT * d, p, last_.seed, s_, st)); gd = gbr_; }
+            if (p > 0.f || dws) { RC(dropout_apply_launch(gx_, into, BT * d, p, last_.seed, s_, st)); gd = into; }
             return 0;
         };
-        RC(drop_gx(site + 4));
-        RC(lin_bwd_w(gd, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d, 1.f, st));
-        RC(lin_bwd_x(gd, d, P(pre + "ffn.2.weight"), gf1_, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st));
-        RC(lin_bwd_w(gf1_, 4 * d, k.ln3, d, G(pre + "ffn.0.weight"), G(pre + "ffn.0.bias"), BT, 4 * d, d, 1.f, st));
-        RC(lin_bwd_x(gf1_, 4 * d, P(pre + "ffn.0.weight"), gt1_, d, BT, 4 * d, d, nullptr, 0, nullptr, 0, st));
+        RC(drop_gx(site + 4, q.gbr[0]));
+        RC(lin_bwd_x(gd, d, P(pre + "ffn.2.weight"), q.gf1, 4 * d, BT, d, 4 * d, k.f1, 4 * d, nullptr, 0, st));
+        RC(dw_sync());
+        RC(dw(gd, d, k.f1, 4 * d, G(pre + "ffn.2.weight"), G(pre + "ffn.2.bias"), BT, d, 4 * d));
+        RC(dw(q.gf1, 4 * d, k.ln3, d, G(pre + "ffn.0.weight"), G(pre + "ffn.0.bias"), BT, 4 * d, d));
+        RC(lin_bwd_x(q.gf1, 4 * d, P(pre + "ffn.0.weight"), gt1_, d, BT, 4 * d, d, nullptr, 0, nullptr, 0, st));
         RC(layernorm_bwd_launch(gt1_, k.x2, k.ln3_mean, k.ln3_rstd, P(pre + "ffn_layer_norm.weight"), gx_, G(pre + "ffn_layer_norm.weight"), BT, d, 1, 0,
                                 scratch_, scratch_floats_, st));
         // ---- cross attention
-        RC(drop_gx(site + 3));
-        RC(lin_bwd_w(gd, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(drop_gx(site + 3, q.gbr[1]));
+        const float* gd_co = gd;
         RC(lin_bwd_x(gd, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d cao
-        RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, gt2_, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, scratch_, scratch_floats_, st));   // gt2 = d cq
-        RC(lin_bwd_w(gt2_, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d, 1.f, st));
-        RC(lin_bwd_x(gt2_, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
+        RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, q.gt2, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, scratch_, scratch_floats_, st));   // gt2 = d cq
+        RC(dw_sync());
+        RC(dw(gd_co, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d));
+        RC(dw(q.gt2, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d));
+        RC(lin_bwd_x(q.gt2, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
         RC(lin_bwd_w(gck_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, BK, d, d, 1.f, st));
         RC(lin_bwd_w(gcv_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, BK, d, d, 1.f, st));
         RC(lin_bwd_x(gck_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, st));
@@ -707,19 +761,21 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         RC(layernorm_bwd_launch(gt1_, k.x1, k.ln2_mean, k.ln2_rstd, P(pre + "encoder_decoder_attn_layer_norm.weight"), gx_,
                                 G(pre + "encoder_decoder_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         // ---- causal self attention
-        RC(drop_gx(site + 1));
-        RC(lin_bwd_w(gd, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d, 1.f, st));
+        RC(drop_gx(site + 1, q.gbr[2]));
+        const float* gd_o = gd;
         RC(lin_bwd_x(gd, d, P(pre + "self_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // gt1 = d ao
         {
             AttnArgs a;
             a.q = k.q; a.k = k.k; a.v = k.v; a.o = k.ao; a.lse = k.lse; a.B = B; a.T = T; a.d = d; a.h = NH; a.ld = 3 * d;
             a.p = p; a.seed = last_.seed; a.site = site + 0;
-            a.dO = gt1_; a.dq = gqkv_; a.dk = gqkv_ + d; a.dv = gqkv_ + 2 * d; a.delta = attn_delta_;
+            a.dO = gt1_; a.dq = q.gqkv; a.dk = q.gqkv + d; a.dv = q.gqkv + 2 * d; a.delta = attn_delta_;
             RC(attn_launch(a, 1, st));
         }
         // fused [3d, d] weight: dW = [dq|dk|dv]^T ln1 ;  d ln1 = [dq|dk|dv] W
-        RC(lin_bwd_w(gqkv_, 3 * d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, 3 * d, d, 1.f, st));
-        RC(lin_bwd_x(gqkv_, 3 * d, P(pre + "self_attn.proj_q.weight"), gt1_, d, BT, 3 * d, d, nullptr, 0, nullptr, 0, st));      // gt1 = d ln1
+        RC(dw_sync());
+        RC(dw(gd_o, d, k.ao, d, G(pre + "self_attn.proj_o.weight"), nullptr, BT, d, d));
+        RC(dw(q.gqkv, 3 * d, k.ln1, d, G(pre + "self_attn.proj_q.weight"), nullptr, BT, 3 * d, d));
+        RC(lin_bwd_x(q.gqkv, 3 * d, P(pre + "self_attn.proj_q.weight"), gt1_, d, BT, 3 * d, d, nullptr, 0, nullptr, 0, st));      // gt1 = d ln1
         if (b == 0) {
             // ln1 is both the attention input and the residual stream: d ln1_total = gx + gt2, then LN backward to emb
             RC(axpy_launch(gx_, gt1_, BT * d, 1.f, st));
@@ -730,7 +786,7 @@ int SlateModel::bwd_decoder(hipStream_t st) {
                                     G(pre + "self_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         }
     }
-    // ---- embedding: gx_ = d emb (after dropout);  dictionary (order-free exact scatter-add), pe / bos (sum over the batch)
+    // ---- embedding: gx_ = d emb (after dropout);  dictionary (rows sorted by token, summed in a fixed order), pe / bos (sum over the batch)
     RC(embed_bwd_launch(gx_, tokens_, G("_dict.dictionary.weight"), B, T, V, d, p, last_.seed, scratch_, scratch_floats_, st));
     RC(fill_launch(G("_z_pos.pe"), (long long)(T + 1) * d, 0.f, st));
     RC(colsum_launch(gx_, (long long)T * d, G("_z_pos.pe"), B, T * d, 0, 1.f, scratch_, scratch_floats_, st));
@@ -759,31 +815,54 @@ int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
         RC(rc);
     }
     RC(slot_attn_launch(a, 1, st));
+    // Everything below that only consumes the slot-attention backward's outputs (gradient rows, dx) and feeds no later kernel of the
+    // step -- the slot-side weight gradients, the LayerNorm partials, the slot-initialisation gradients and the weight gradient of the
+    // input MLP's second layer -- goes to the side stream; the main stream continues with the input-gradient chain towards the
+    // convolutions.  Joined at the end of the backward.
+    const bool side_w = side_ && overlap_mode_ >= 3 && !cfg.use_bcdec && !fork_dvae;
+    hipStream_t sw = side_w ? side_ : st;
+    if (side_w) { RC(fork_side(st)); std::swap(scratch_, scratch2_); }
+    auto sa_weight_grads = [&]() -> int {
     // weight gradients: contract the emitted gradient rows with the saved activations over (image, iteration, slot)
-    RC(lin_bwd_w(sa_grows_ + go.out, go.ld, sa_save_ + so.hid, so.ld, G(sa + "mlp.2.weight"), G(sa + "mlp.2.bias"), R, D, H, 1.f, st));
-    RC(lin_bwd_w(sa_grows_ + go.hid, go.ld, sa_save_ + so.m, so.ld, G(sa + "mlp.0.weight"), G(sa + "mlp.0.bias"), R, H, D, 1.f, st));
-    RC(lin_bwd_w(sa_grows_ + go.gi, go.ld, sa_save_ + so.u, so.ld, G(sa + "gru.weight_ih"), G(sa + "gru.bias_ih"), R, 3 * D, D, 1.f, st));
-    RC(lin_bwd_w(sa_grows_ + go.gh, go.ld, sa_save_ + so.sprev, so.ld, G(sa + "gru.weight_hh"), G(sa + "gru.bias_hh"), R, 3 * D, D, 1.f, st));
-    RC(lin_bwd_w(sa_grows_ + go.u, go.ld, sa_save_ + so.up, so.ld, G(sa + "project_v.weight"), nullptr, R, D, C, 1.f, st));
-    RC(lin_bwd_w(sa_grows_ + go.q, go.ld, sa_save_ + so.sn, so.ld, G(sa + "project_q.weight"), nullptr, R, D, D, 1.f, st));
-    RC(lin_bwd_w(sa_save_ + so.q, so.ld, sa_grows_ + go.qp, go.ld, G(sa + "project_k.weight"), nullptr, R, D, C, a.scale, st));
+    RC(lin_bwd_w(sa_grows_ + go.out, go.ld, sa_save_ + so.hid, so.ld, G(sa + "mlp.2.weight"), G(sa + "mlp.2.bias"), R, D, H, 1.f, sw));
+    RC(lin_bwd_w(sa_grows_ + go.hid, go.ld, sa_save_ + so.m, so.ld, G(sa + "mlp.0.weight"), G(sa + "mlp.0.bias"), R, H, D, 1.f, sw));
+    RC(lin_bwd_w(sa_grows_ + go.gi, go.ld, sa_save_ + so.u, so.ld, G(sa + "gru.weight_ih"), G(sa + "gru.bias_ih"), R, 3 * D, D, 1.f, sw));
+    RC(lin_bwd_w(sa_grows_ + go.gh, go.ld, sa_save_ + so.sprev, so.ld, G(sa + "gru.weight_hh"), G(sa + "gru.bias_hh"), R, 3 * D, D, 1.f, sw));
+    RC(lin_bwd_w(sa_grows_ + go.u, go.ld, sa_save_ + so.up, so.ld, G(sa + "project_v.weight"), nullptr, R, D, C, 1.f, sw));
+    RC(lin_bwd_w(sa_grows_ + go.q, go.ld, sa_save_ + so.sn, so.ld, G(sa + "project_q.weight"), nullptr, R, D, D, 1.f, sw));
+    RC(lin_bwd_w(sa_save_ + so.q, so.ld, sa_grows_ + go.qp, go.ld, G(sa + "project_k.weight"), nullptr, R, D, C, a.scale, sw));
     const int SM = 4 * D + 2 * C;
-    RC(colsum_launch(sa_small_ + 0, SM, G(sa + "norm_slots.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, st));
-    RC(colsum_launch(sa_small_ + 2 * D, SM, G(sa + "norm_mlp.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, st));
-    RC(colsum_launch(sa_small_ + 4 * D, SM, G(sa + "norm_inputs.weight"), B, 2 * C, 0, 1.f, scratch_, scratch_floats_, st));
+    RC(colsum_launch(sa_small_ + 0, SM, G(sa + "norm_slots.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, sw));
+    RC(colsum_launch(sa_small_ + 2 * D, SM, G(sa + "norm_mlp.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, sw));
+    RC(colsum_launch(sa_small_ + 4 * D, SM, G(sa + "norm_inputs.weight"), B, 2 * C, 0, 1.f, scratch_, scratch_floats_, sw));
     RC(slot_init_bwd_launch(gslots0_, P("_slotattn.slot_log_sigma"), last_.noise_slots, G("_slotattn.slot_mu"), G("_slotattn.slot_log_sigma"),
-                            B * K, D, last_.seed, st));
+                            B * K, D, last_.seed, sw));
     // ---- input MLP: x = W2 relu(W0 LN(e4) + b0) + b2 ; gA = dx
-    RC(lin_bwd_w(gA_, C, h1_, C, G("_slotattn.mlp.2.weight"), G("_slotattn.mlp.2.bias"), BN, C, C, 1.f, st));
+    RC(lin_bwd_w(gA_, C, h1_, C, G("_slotattn.mlp.2.weight"), G("_slotattn.mlp.2.bias"), BN, C, C, 1.f, sw));
+    // the first convolution's weight gradient is a product with im2col(obs): the patch matrix only needs the observation
+    if (side_w) RC(im2col5_launch(obs8_, col0_, BN, S, S, cfg.obs_channels, (25 * cfg.obs_channels + 3) & ~3, sw));
+    return 0;
+    };
+    {
+        const int rc = sa_weight_grads();
+        if (side_w) std::swap(scratch_, scratch2_);
+        RC(rc);
+    }
     RC(lin_bwd_x(gA_, C, P("_slotattn.mlp.2.weight"), gB_, C, BN, C, C, h1_, C, nullptr, 0, st));              // gB = d h1 (pre-relu)
     RC(lin_bwd_w(gB_, C, ln0_, C, G("_slotattn.mlp.0.weight"), G("_slotattn.mlp.0.bias"), BN, C, C, 1.f, st));
-    RC(lin_bwd_x(gB_, C, P("_slotattn.mlp.0.weight"), gA_, C, BN, C, C, nullptr, 0, nullptr, 0, st));           // gA = d ln0
-    RC(layernorm_bwd_launch(gA_, e4_, ln0_mean_, ln0_rstd_, P("_slotattn.layer_norm.weight"), gB_, G("_slotattn.layer_norm.weight"), BN, C, 0, 0,
+    // d ln0 goes to gC_ when the side stream may still be reading gA_ (= dx) for the second layer's weight gradient
+    float* gL = side_w ? gC_ : gA_;
+    RC(lin_bwd_x(gB_, C, P("_slotattn.mlp.0.weight"), gL, C, BN, C, C, nullptr, 0, nullptr, 0, st));            // gL = d ln0
+    RC(layernorm_bwd_launch(gL, e4_, ln0_mean_, ln0_rstd_, P("_slotattn.layer_norm.weight"), gB_, G("_slotattn.layer_norm.weight"), BN, C, 0, 0,
                             scratch_, scratch_floats_, st));                                                      // gB = d e4
     // ---- positional embedding (added to every image): d map = sum over images
     RC(colsum_launch(gB_, (long long)N * C, gmap_, B, N * C, 0, 1.f, scratch_, scratch_floats_, st));
     RC(lin_bwd_w(gmap_, C, gridT_, 4, G("_enc_pos.channels_map.weight"), G("_enc_pos.channels_map.bias"), N, C, 4, 1.f, st));
-    if (fork_dvae) RC(join_side(st));
+    if (fork_dvae || side_w) RC(join_side(st));          // the side stream has read gA_ (= dx): the convolution chain may reuse it
+    if (dw_mode_ == 2 && side2_) {                       // ... and the decoder's weight gradients are done: the convolutions run alone
+        OCRL_HIP(hipEventRecord(ev_join2_, side2_));
+        OCRL_HIP(hipStreamWaitEvent(st, ev_join2_, 0));
+    }
     // ---- CNN encoder, last layer first
     // the last layer's bias gradient is the column sum of the per-position sums gmap_ just taken for the positional embedding (4 MB),
     // not another pass over the [B*N, 64] gradient (537 MB)
@@ -798,7 +877,7 @@ int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
     // dW = dY^T im2col(obs) it is one [64 x 75] split-K product over the B*N pixels
     {
         const int ch = cfg.obs_channels, ldc0 = (25 * ch + 3) & ~3;
-        RC(im2col5_launch(obs8_, col0_, BN, S, S, ch, ldc0, st));
+        if (!side_w) RC(im2col5_launch(obs8_, col0_, BN, S, S, ch, ldc0, st));
         RC(lin_bwd_w(gA_, 64, col0_, ldc0, dw0p_, G("_enc._encoder.0.m.bias"), BN, 64, ldc0, 1.f, st));
         RC(unpack5_launch(dw0p_, G("_enc._encoder.0.m.weight"), ch, ldc0, st));
     }
@@ -898,7 +977,9 @@ int SlateModel::backward(hipStream_t st) {
         std::swap(scratch_, scratch2_);
         RC(rc);
         RC(bwd_decoder(st));
-        RC(join_side(st));
+        // with the decoder's weight gradients on the side stream (OCRL_DW_SIDE) that stream may still be busy: it is joined inside
+        // bwd_encoder, before the convolutions, so the slot-attention backward and the input MLP overlap what is left of it
+        if (!dw_mode_) RC(join_side(st));
         RC(bwd_encoder(st));
     } else if (side_) {         // the dVAE backward only needs the forward's reconstruction gradient: it overlaps decoder + encoder
         RC(fork_side(st));

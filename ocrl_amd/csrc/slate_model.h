@@ -144,12 +144,23 @@ private:
         float *ln3, *ln3_mean, *ln3_rstd, *f1, *x3;
     };
     std::vector<Blk> blk_;
+    // per-block gradient temporaries that a weight-gradient product on the side stream may still be reading while the main stream has
+    // moved on: the dropout-backward copies of the residual gradient at the three branch outputs, d ffn-hidden, d cross-attention query,
+    // d q|k|v (OCRL_DW_SIDE; without it every block uses the first set)
+    struct BlkG { float *gbr[3], *gf1, *gt2, *gqkv; };
+    std::vector<BlkG> bg_;
+    int dw_mode_ = 0;                     // OCRL_DW_SIDE: 0 weight gradients of the decoder on the main stream, 1 on the dVAE side stream, 2 on a stream of their own
+    hipStream_t side2_ = nullptr;
+    float* scratch3_ = nullptr;
+    hipEvent_t ev_dw_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join2_ = nullptr;
+    int ev_dw_next_ = 0;
     float *attn_delta_;                   // [B,h,T] scratch of the attention backward
     float *lnf_, *lnf_mean_, *lnf_rstd_, *pred_;
     // gradient temporaries
     float *gqkv_;                         // [BT, 3d] fused dq|dk|dv
     float *gx_, *gbr_, *gt1_, *gt2_, *gt3_, *gf1_, *gmem_, *gck_, *gcv_, *gslots_, *gslots0_;
-    float *gA_, *gB_;                     // [B*N,64] (CNN encoder / slot-attention input gradients)
+    float *gA_, *gB_, *gC_;               // [B*N,64] (CNN encoder / slot-attention input gradients)
     float *gdA_, *gdB_;                   // dVAE decoder gradient ping-pong (up to [B*4T,256])
     float *gmap_;
     float *col0_, *dw0p_;                 // first conv layer: im2col of the observation and the [64, 25*ch (+pad)] gradient product

@@ -939,8 +939,8 @@ static int sa_launch_kg(const SlotAttnArgs& a, int backward, hipStream_t st) {
     const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
     if (!backward) {
         const size_t smem_stream = (size_t)(KP * SA_C + 16 + (SA_TS / 64) * 16 * SA_TLD) * 4;
-        hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
-        for (int t = 0; t < a.I; ++t) {
+        if (a.phase != 2) hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
+        for (int t = 0; t < a.I && a.phase != 1; ++t) {
             hipLaunchKernelGGL((sa_stream_fwd_kernel<K>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, t, NS);
             hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, t, NS);
         }
