@@ -278,6 +278,134 @@ __device__ __forceinline__ void sa_stream_fwd(const float4* __restrict__ xb, int
     }
 }
 
+// ------------------------------------------------------------------------------------------- forward streaming pass, second form
+// Same products, transposed: logits^T[slot][pos] = q' . d^T, so that a lane holds its OWN position's logits of four slots in its four
+// accumulator registers (lane = (pos li, slot group g'), register r = slot 4g' + r).  The soft-max over the slots is then in-lane
+// arithmetic plus one or two cross-row exchanges (v_permlane16/32_swap, VALU speed) instead of two 4-step DPP reductions per
+// register; the LayerNorm scale rstd[pos] is lane-local and is folded into the logits (acc * rstd + bias) and into the weights of the
+// second product (w * rstd), so x is only centred, not normalised; q' arrives pre-multiplied by log2(e) and the exponentials are bare
+// v_exp_f32; the quotient is a v_rcp_f32.  The weights go through a 16x16 LDS patch to reach the operand layout of the second product
+// (4 ds_write_b32 + 1 ds_read_b128).  Measured on the round-2 form: ~300 VALU instructions per 16-position tile against 32 MFMAs, i.e.
+// VALU-bound with the matrix pipe 38 % busy; this form needs ~120.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define SA_WT_LD 20       // row stride of the per-wave [16 slots][16 positions] weight patch
+#define SA_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float sa_xrow16(float v, bool is_max) {      // combine with the lane 16 apart (rows 0<->1, 2<->3)
+    const int a = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+    const float x = __builtin_bit_cast(float, (int)r[0]), y = __builtin_bit_cast(float, (int)r[1]);
+    return is_max ? __builtin_amdgcn_fmed3f(x, y, INFINITY) : x + y;
+}
+__device__ __forceinline__ float sa_xrow32(float v, bool is_max) {      // combine with the lane 32 apart (rows 0<->2, 1<->3)
+    const int a = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);
+    const float x = __builtin_bit_cast(float, (int)r[0]), y = __builtin_bit_cast(float, (int)r[1]);
+    return is_max ? __builtin_amdgcn_fmed3f(x, y, INFINITY) : x + y;
+}
+__device__ __forceinline__ float sa_xrow_sum4(float v) { return sa_xrow32(sa_xrow16(v, false), false); }    // over the 4 lanes of a position
+template <int K>
+__device__ __forceinline__ void sa_stream_fwd2(const float4* __restrict__ xb, int N, const float* qg, const float* qb, float eps, float* attn_out,
+                                               float* tiles, float* scr, int tile0, int tile1) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
+    float* tile = tiles + wv * (16 * SA_TLD + 16 * SA_WT_LD);
+    float* wt = tile + 16 * SA_TLD;
+    float qpr[16];                                       // A operand of the logits: q'[slot li][channel 16(k>>2) + 4g + (k&3)] * log2(e)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) qpr[k] = li < K ? qg[li * SA_C + 16 * (k >> 2) + 4 * g + (k & 3)] * SA_LOG2E : 0.f;
+    float qbr[4];                                        // bias of slot 4g + r in log2 units; padding slots sit at -1e30 (their weight is 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qbr[r] = 4 * g + r < K ? qb[4 * g + r] * SA_LOG2E : -1e30f;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};                  // sum over this lane's positions of w[slot 4g + r]
+    const int ntile = tile1;
+    float4 bufA[4], bufB[4];
+    if (tile0 + wv < ntile) sa_load_tile(xb, N, tile0 + wv, li, g, bufA);
+    if (tile0 + wv + nw < ntile) sa_load_tile(xb, N, tile0 + wv + nw, li, g, bufB);
+    auto tile_step = [&](float4 (&cur)[4], int t) {
+        // ---- LayerNorm statistics of position li (its 64 channels sit in the four lanes li, li+16, li+32, li+48)
+        f32x2_t v2[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v2[2 * c] = (f32x2_t){cur[c].x, cur[c].y}; v2[2 * c + 1] = (f32x2_t){cur[c].z, cur[c].w}; }
+        if (t + 2 * nw < ntile) sa_load_tile(xb, N, t + 2 * nw, li, g, cur);
+        f32x2_t s2 = ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
+        const float mu = sa_xrow_sum4(s2.x + s2.y) * (1.0f / SA_C);
+        const f32x2_t mu2 = (f32x2_t){mu, mu};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v2[k] -= mu2;
+        f32x2_t q2 = v2[0] * v2[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) q2 = __builtin_elementwise_fma(v2[k], v2[k], q2);
+        const float rs = __builtin_amdgcn_rsqf(sa_xrow_sum4(q2.x + q2.y) * (1.0f / SA_C) + 1e-5f);
+        // ---- logits^T = q' d^T in two independent chains (the centred x is the B operand: [k = channel group][n = position])
+        f32x4_t La = (f32x4_t){0.f, 0.f, 0.f, 0.f}, Lb = La;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            La = MFMA16(qpr[2 * k], v2[k].x, La);
+            Lb = MFMA16(qpr[2 * k + 1], v2[k].y, Lb);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<float4*>(tile + li * SA_TLD + 16 * c + 4 * g) = make_float4(v2[2 * c].x, v2[2 * c].y, v2[2 * c + 1].x, v2[2 * c + 1].y);
+        // ---- soft-max over the slots of position li: registers, then across the slot groups
+        float l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) l[r] = __builtin_fmaf(La[r] + Lb[r], rs, qbr[r]);
+        float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+        mx = sa_xrow16(mx, true);
+        if (K > 8) mx = sa_xrow32(mx, true);
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(l[r] - mx);
+        float sm = (e[0] + e[1]) + (e[2] + e[3]);
+        sm = sa_xrow16(sm, false);
+        if (K > 8) sm = sa_xrow32(sm, false);
+        const float inv = __builtin_amdgcn_rcpf(sm);
+        const int pos = t * 16 + li;
+        const float live = pos < N ? 1.f : 0.f;              // only the ragged last tile has dead positions
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w[r] = __builtin_fmaf(e[r], inv, eps) * live;
+            cs[r] += w[r];
+            wt[(4 * g + r) * SA_WT_LD + li] = w[r] * rs;      // [slot][position]
+        }
+        if (attn_out && pos < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r < K) attn_out[pos * K + 4 * g + r] = e[r] * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float4 wb4 = *reinterpret_cast<const float4*>(wt + li * SA_WT_LD + 4 * g);      // w rstd of slot li at positions 4g .. 4g+3
+        const float wb[4] = {wb4.x, wb4.y, wb4.z, wb4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(tile[(4 * g + r) * SA_TLD + 16 * m + li], wb[r], acc[m]);   // sum_n (w rstd) d^T: [ch][slot]
+        __builtin_amdgcn_wave_barrier();
+    };
+#pragma unroll 1
+    for (int t = tile0 + wv; t < ntile; t += 2 * nw) {
+        tile_step(bufA, t);
+        if (t + nw < ntile) tile_step(bufB, t + nw);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[r] = red16_sum(cs[r]);      // over the 16 positions of the row: every lane of row g holds slot 4g + r
+    __syncthreads();          // every wave is done with its tile: the region is reused for the partials
+    if (li < K) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[(wv * K + li) * (SA_C + 1) + 16 * m + 4 * g + r] = acc[m][r];
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < K) scr[(wv * K + 4 * g + r) * (SA_C + 1) + SA_C] = cs[r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------- slot side: geometry
 // The slot-side kernels run their matrix products on 16-row MFMA tiles.  With K <= 8 slots per image a workgroup therefore takes
 // G = 16 / K images at once: the G*K slot rows fill the tile, so every weight element fetched from L2 and every MFMA issued serves G
@@ -454,7 +582,7 @@ __host__ __device__ inline size_t sa_xchg_floats(int K, int D) {
     return ((size_t)KI * D + (size_t)KI * SA_C + 16 + 15) & ~(size_t)15;
 }
 #define SA_TS 256        // streaming workgroup: 4 waves
-template <int K>
+template <int K, bool V2>
 __global__ __launch_bounds__(SA_TS, 3) void sa_stream_fwd_kernel(SlotAttnArgs p, int t, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int C = SA_C, KP = SaBlk<K>::KP;
@@ -470,7 +598,9 @@ __global__ __launch_bounds__(SA_TS, 3) void sa_stream_fwd_kernel(SlotAttnArgs p,
     const float4* xb = reinterpret_cast<const float4*>(p.x + (size_t)b * N * C);
     const int ntile = (N + 15) / 16, per = (ntile + NS - 1) / NS;
     const int t0 = h * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
-    sa_stream_fwd<K>(xb, N, qg, qb, p.eps, (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr, tiles, tiles, t0, t1 > t0 ? t1 : t0);
+    float* attn_out = (t == p.I - 1 && p.attn) ? p.attn + (size_t)b * N * K : nullptr;
+    if (V2) sa_stream_fwd2<K>(xb, N, qg, qb, p.eps, attn_out, tiles, tiles, t0, t1 > t0 ? t1 : t0);
+    else sa_stream_fwd<K>(xb, N, qg, qb, p.eps, attn_out, tiles, tiles, t0, t1 > t0 ? t1 : t0);
     __syncthreads();
     float* part = p.parts + ((size_t)b * NS + h) * K * (C + 1);
     for (int i = tid; i < K * (C + 1); i += nt) {          // this workgroup's partial: sum over its waves, fixed order
@@ -938,10 +1068,13 @@ static int sa_launch_kg(const SlotAttnArgs& a, int backward, hipStream_t st) {
     const int ngrp = (a.B + G - 1) / G;
     const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
     if (!backward) {
-        const size_t smem_stream = (size_t)(KP * SA_C + 16 + (SA_TS / 64) * 16 * SA_TLD) * 4;
+        static int fwd_form = -1;          // OCRL_SA_FWD=1: the round-2 streaming forward (slots on the lanes); default: positions on the lanes
+        if (fwd_form < 0) { const char* e = getenv("OCRL_SA_FWD"); fwd_form = e ? atoi(e) : 2; }
+        const size_t smem_stream = (size_t)(KP * SA_C + 16 + (SA_TS / 64) * (16 * SA_TLD + 16 * SA_WT_LD)) * 4;
         if (a.phase != 2) hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
         for (int t = 0; t < a.I && a.phase != 1; ++t) {
-            hipLaunchKernelGGL((sa_stream_fwd_kernel<K>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, t, NS);
+            if (fwd_form == 1) hipLaunchKernelGGL((sa_stream_fwd_kernel<K, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, t, NS);
+            else hipLaunchKernelGGL((sa_stream_fwd_kernel<K, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, t, NS);
             hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, t, NS);
         }
     } else {

@@ -81,11 +81,13 @@ def build_wrapper(cfg, P, use_cnn_feat=False, device="cuda:0"):
 # of either implementation, so the gradient comparison holds the ReLU decisions fixed: the oracle is evaluated in fp64 with the
 # masks of the HIP forward (read from its saved activations), and every tensor must then agree tightly.
 # ---------------------------------------------------------------------------------------------------------------------------
-def hip_relu_masks(eng, cfg, B):
-    """bool masks of every ReLU of the HIP forward, in the order and tensor layout of the oracle's F.relu calls (slate_loss)"""
+def hip_relu_acts(eng, cfg, B, images=None):
+    """post-ReLU activations of the HIP forward (zero where the unit is closed), in the order and tensor layout of the oracle's F.relu
+    calls (slate_loss); `images` restricts the batch dimension (a slice) before the copy to the host"""
     S, E = cfg.obs_size, cfg.obs_size // 4
     T, N, K, I, H, d = E * E, S * S, cfg.num_slots, cfg.num_iterations, cfg.mlp_hidden, cfg.d_model
-    nchw = lambda t: (t > 0).permute(0, 3, 1, 2).cpu()
+    sl = images if images is not None else slice(None)
+    nchw = lambda t: t[sl].permute(0, 3, 1, 2).cpu()
     out = []
     if cfg.use_bcdec:       # the oracle (like the reference) still runs the dVAE here; the HIP path skips that dead work: plain ReLU for those calls
         out += [None] * 16
@@ -97,18 +99,24 @@ def hip_relu_masks(eng, cfg, B):
             out.append(nchw(eng.tensor(name, (B, hh, hh, c))))
     for name in ("enc1", "enc2", "enc3"):
         out.append(nchw(eng.tensor(name, (B, S, S, 64))))
-    out.append((eng.tensor("sa_mlp_hidden", (B, N, 64)) > 0).cpu())
+    out.append(eng.tensor("sa_mlp_hidden", (B, N, 64))[sl].cpu())
     ld = 10 * cfg.slot_size + H + 3 * 64 + 4                                  # kernels.h sa_save_layout
     sv = eng.tensor("sa_save", (B, I, K, ld))[..., 10 * cfg.slot_size:10 * cfg.slot_size + H]
     for t in range(I):
-        out.append((sv[:, t] > 0).cpu())
+        out.append(sv[sl, t].cpu())
     if cfg.use_bcdec:
+        ks = slice(None) if images is None else slice((images.start or 0) * K, (images.stop or B) * K)
         for name in ("bc_c1", "bc_c2", "bc_c3"):
-            out.append(nchw(eng.tensor(name, (B * K, S, S, 64))))
+            out.append(eng.tensor(name, (B * K, S, S, 64))[ks].permute(0, 3, 1, 2).cpu())
     else:
         for b in range(cfg.num_dec_blocks):
-            out.append((eng.tensor(f"blk{b}.ffn_hidden", (B, T, 4 * d)) > 0).cpu())
+            out.append(eng.tensor(f"blk{b}.ffn_hidden", (B, T, 4 * d))[sl].cpu())
     return out
+
+
+def hip_relu_masks(eng, cfg, B):
+    """bool masks of every ReLU of the HIP forward, in the order and tensor layout of the oracle's F.relu calls (slate_loss)"""
+    return [None if a is None else a > 0 for a in hip_relu_acts(eng, cfg, B)]
 
 
 class ForcedRelu:

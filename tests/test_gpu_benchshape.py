@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from oracle import slate_oracle as O          # closed-form weights and the schedules only
-from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_masks, load_params, log, relerr
+from tests.gpu_util import dims_from_cfg, grad_floor, hip_relu_acts, load_params, log, relerr
 from tests.test_gpu_slate import GRAD_TOL
 
 pytestmark = pytest.mark.gpu
@@ -48,9 +48,9 @@ def _one_image_noise(cfg, seed):
                 slots=torch.randn(1, K, D, device="cuda", generator=g))
 
 
-def _masks_image0(eng, cfg, nb):
-    """ReLU decisions of image 0 (hip_relu_masks reads whole-batch tensors; only the first image is kept)"""
-    return [m[:1].clone() for m in hip_relu_masks(eng, cfg, nb)]
+def _acts_image0(eng, cfg, nb):
+    """post-ReLU activations of image 0 at every ReLU site"""
+    return [a.clone() for a in hip_relu_acts(eng, cfg, nb, images=slice(0, 1))]
 
 
 @pytest.mark.parametrize("tag,over", CONFIGS)
@@ -76,7 +76,7 @@ def test_replicated_image_equals_single_image_engine(tag, over):
         out = dict(m=eng.metrics.cpu().clone().double(), tokens=eng.tensor("tokens", (nb, T), torch.int32).cpu().clone(),
                    slots=eng.tensor("slots", (nb, K, D)).cpu().clone(), attn=eng.tensor("attn", (nb, N, K)).cpu().clone(),
                    recon=eng.tensor("recon", (nb, S, S, 4))[..., :3].cpu().clone(), dec_out=eng.tensor("dec_out", (nb, T, cfg.d_model)).cpu().clone())
-        out["masks"] = _masks_image0(eng, cfg, nb)
+        out["acts"] = _acts_image0(eng, cfg, nb)
         eng.backward()
         torch.cuda.synchronize()
         out["g"] = eng.flat_g.cpu().clone()
@@ -108,17 +108,23 @@ def test_replicated_image_equals_single_image_engine(tag, over):
     for k in ("slots", "recon"):
         spread = (rep[k] - rep[k][:1]).abs().max().item() / rep[k][0].abs().max().item()
         assert spread < 1e-6, (k, spread)
-    # ReLU decisions of image 0 in both runs
-    flips, units = 0, 0
-    for a, b_ in zip(one["masks"], rep["masks"]):
-        flips += int((a != b_).sum())
+    # ReLU decisions of image 0 in both runs: they may differ only at rounding ties (a unit closed in one run and open by less than 1e-5
+    # in the other); one such flip moves the weight gradients upstream of it by ~1/T of their maximum (measured at config Z: one flip in
+    # 4.1e7 units, 1.2e-3 on _tfdec.blocks.1.ffn.0.weight), so the gradient is graded tightly only when there is none
+    flips, units, edge = 0, 0, 0.0
+    for a, b_ in zip(one["acts"], rep["acts"]):
+        diff = (a > 0) != (b_ > 0)
+        n = int(diff.sum())
         units += a.numel()
-    assert flips <= 4, (flips, units)
+        if n:
+            flips += n
+            edge = max(edge, float(torch.maximum(a, b_)[diff].max()))
+    assert flips <= 4 and edge <= 1e-5, (flips, units, edge)
     # gradient: sum over 128 equal images / 128 == the single image's gradient
     gmax = one["g"].abs().max().item()
     rows = sorted(((relerr(rep["view"](rep["g"], p), one["view"](one["g"], p), floor=grad_floor(p.name, gmax)), p.name) for p in one["params"]), reverse=True)
-    tol = GRAD_TOL if flips == 0 else 1e-3
-    log(f"[{tag}] gradient of the replicated batch vs B=1: worst {rows[0][0]:.2e} ({rows[0][1]}); {flips} of {units} ReLU decisions of image 0 differ; "
+    tol = GRAD_TOL if flips == 0 else 5e-3
+    log(f"[{tag}] gradient of the replicated batch vs B=1: worst {rows[0][0]:.2e} ({rows[0][1]}); {flips} of {units} ReLU decisions of image 0 differ (largest open value among them {edge:.1e}); "
         f"tolerance {tol:.0e}; top: " + "; ".join(f"{n}={e:.1e}" for e, n in rows[:4]))
     assert rows[0][0] < tol, rows[:5]
 
