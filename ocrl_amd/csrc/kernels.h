@@ -129,6 +129,36 @@ int im2col5_launch(const float* x8, float* col, long long npix, int H, int W, in
 int unpack5_launch(const float* dWp, float* dW, int C, int ldc, hipStream_t st);
 int pad_cols_launch(const float* in, int ldi, float* out, int ldo, long long R, int C, int Cout, hipStream_t st);
 
+// ------------------------------------------------------------------ xattn.hip: cross attention to the slots, folded (transformer.py:23-50,181-185)
+bool xattn_supported(int K, int d, int h);
+int xattn_kp(int K, int h);                       // slots per head after padding (8 or 16); columns NC = h * KP
+struct XaFoldHost {                               // per-image operands of all decoder blocks from the projected slots, one launch
+    const float* mem = nullptr;                   // [B,K,d]
+    const float* Wq[8]; const float* Wk[8]; const float* Wv[8]; const float* Wo[8];     // [d,d] (out, in) per block
+    float* ck[8]; float* cv[8];                   // [B,K,d]
+    float* Ab[8]; float* AbT[8]; float* Vo[8]; float* VoT[8];     // [B,NC,d] / [B,d,NC]; padding columns must be zero (never written)
+    int B = 0, K = 0, d = 0, h = 0, nblk = 0;
+};
+int xattn_fold_fwd_launch(const XaFoldHost& f, hipStream_t st);
+struct XaHost {
+    const float* x = nullptr;                     // [B,T,d] attention input (LN of the residual stream)
+    const float* resid = nullptr;                 // forward: residual stream
+    float* y = nullptr;                           // forward: resid + dropout(out);  backward: d x
+    float* P = nullptr;                           // [B,h,T,K] probabilities before dropout
+    const float *Ab = nullptr, *AbT = nullptr, *Vo = nullptr, *VoT = nullptr;
+    const float* gd = nullptr;                    // backward: gradient wrt out
+    float *Pd = nullptr, *dS = nullptr;           // backward: [B*T, NC]
+    int B = 0, T = 0, K = 0, d = 0, h = 0;
+    float p = 0.f; unsigned long long seed = 0; unsigned site_p = 0, site_o = 0;
+};
+int xattn_launch(const XaHost& h, int backward, hipStream_t st);
+struct XaFoldBwdHost {
+    const float *dAb = nullptr, *dVo = nullptr, *ck = nullptr, *cv = nullptr, *Wq = nullptr, *Wo = nullptr;
+    float *dck = nullptr, *dcv = nullptr, *dWq_part = nullptr, *dWo_part = nullptr;      // [B,K,d] x2, [B,d,d] x2
+    int B = 0, K = 0, d = 0, h = 0;
+};
+int xattn_fold_bwd_launch(const XaFoldBwdHost& f, hipStream_t st);
+
 // ------------------------------------------------------------------ slot_attn.hip
 // Packed weight block (built once per step by pack_launch): originals and transposed copies.
 struct SaWts {

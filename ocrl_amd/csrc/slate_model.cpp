@@ -219,6 +219,18 @@ void SlateModel::layout_workspace(bool commit) {
         k.ln3 = carve(nullptr, BT * d); k.ln3_mean = carve(nullptr, BT); k.ln3_rstd = carve(nullptr, BT);
         k.f1 = carve(fmt("blk%d.ffn_hidden", b).c_str(), BT * 4 * d); k.x3 = carve(nullptr, BT * d);
     }
+    {   // folded cross attention (xattn.hip)
+        const size_t NC = xattn_supported(K, d, NH) ? (size_t)NH * xattn_kp(K, NH) : 16;
+        xa_zero_base_ = reinterpret_cast<float*>(ws_ + ws_off_);
+        for (int b = 0; b < NB; ++b) {
+            Blk& k = blk_[b];
+            k.xaAb = carve(nullptr, B * NC * d); k.xaAbT = carve(nullptr, B * NC * d); k.xaVo = carve(nullptr, B * NC * d); k.xaVoT = carve(nullptr, B * NC * d);
+        }
+        xa_zero_floats_ = (size_t)(reinterpret_cast<float*>(ws_ + ws_off_) - xa_zero_base_);
+        xa_Pd_ = carve(nullptr, BT * NC); xa_dS_ = carve(nullptr, BT * NC);
+        xa_dAb_ = carve(nullptr, B * NC * d); xa_dVo_ = carve(nullptr, B * NC * d);
+        xa_pq_ = carve(nullptr, B * (size_t)d * d); xa_po_ = carve(nullptr, B * (size_t)d * d);
+    }
     attn_delta_ = carve(nullptr, B * NH * (size_t)T);
     lnf_ = carve("dec_out", BT * d); lnf_mean_ = carve(nullptr, BT); lnf_rstd_ = carve(nullptr, BT);
     pred_ = carve("pred", BT * V);
@@ -282,6 +294,11 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
                 if (dw_mode_ == 2) OCRL_HIP(hipStreamCreateWithFlags(&side2_, hipStreamNonBlocking));
             }
         }
+    }
+    {
+        const char* e = getenv("OCRL_XATTN");
+        xattn_ = !cfg.use_bcdec && xattn_supported(K, d, NH) && (e ? atoi(e) != 0 : true);
+        if (!cfg.use_bcdec && xa_zero_floats_) OCRL_HIP(hipMemset(xa_zero_base_, 0, xa_zero_floats_ * sizeof(float)));      // padding columns of the folded operands
     }
     // static tables
     RC(posgrid_launch(gridT_, S, 0));
@@ -530,6 +547,17 @@ int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
     const float scale = 1.0f / sqrtf((float)DH);
     RC(lin_fwd(slots_, D, P("_slotproj.weight"), nullptr, mem_, d, (long long)B * K, d, D, 0, nullptr, 0, 0.f, 0, st));
     RC(embed_fwd_launch(tokens_, P("_dict.dictionary.weight"), P("_bos_token._bos_token"), P("_z_pos.pe"), emb_, B, T, d, p, last_.seed, st));
+    if (xattn_) {       // per-image cross-attention operands of every block from the projected slots: one launch
+        XaFoldHost f;
+        f.mem = mem_; f.B = B; f.K = K; f.d = d; f.h = NH; f.nblk = NB;
+        OCRL_REQUIRE(NB <= 8, "more than 8 decoder blocks: set OCRL_XATTN=0");
+        for (int b = 0; b < NB; ++b) {
+            const std::string pre = fmt("_tfdec.blocks.%d.encoder_decoder_attn.", b);
+            f.Wq[b] = P(pre + "proj_q.weight"); f.Wk[b] = P(pre + "proj_k.weight"); f.Wv[b] = P(pre + "proj_v.weight"); f.Wo[b] = P(pre + "proj_o.weight");
+            f.ck[b] = blk_[b].ck; f.cv[b] = blk_[b].cv; f.Ab[b] = blk_[b].xaAb; f.AbT[b] = blk_[b].xaAbT; f.Vo[b] = blk_[b].xaVo; f.VoT[b] = blk_[b].xaVoT;
+        }
+        RC(xattn_fold_fwd_launch(f, st));
+    }
     const float* xin = emb_;
     for (int b = 0; b < NB; ++b) {
         Blk& k = blk_[b];
@@ -548,11 +576,18 @@ int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
         RC(lin_fwd(k.ao, d, P(pre + "self_attn.proj_o.weight"), nullptr, k.x1, d, BT, d, d, 0, res, d, p, site + 1, st));
         // cross attention to the projected slots
         RC(layernorm_fwd_launch(k.x1, P(pre + "encoder_decoder_attn_layer_norm.weight"), P(pre + "encoder_decoder_attn_layer_norm.bias"), k.ln2, k.ln2_mean, k.ln2_rstd, BT, d, st));
+        if (xattn_) {       // folded form: scores, soft-max, dropout, output, dropout and the residual add in one launch (xattn.hip)
+            XaHost hx;
+            hx.x = k.ln2; hx.resid = k.x1; hx.y = k.x2; hx.P = k.cP; hx.Ab = k.xaAb; hx.AbT = k.xaAbT; hx.Vo = k.xaVo; hx.VoT = k.xaVoT;
+            hx.B = B; hx.T = T; hx.K = K; hx.d = d; hx.h = NH; hx.p = p; hx.seed = last_.seed; hx.site_p = site + 2; hx.site_o = site + 3;
+            RC(xattn_launch(hx, 0, st));
+        } else {
         RC(lin_fwd(k.ln2, d, P(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, k.cq, d, BT, d, d, 0, nullptr, 0, 0.f, 0, st));
         RC(lin_fwd(mem_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, k.ck, d, (long long)B * K, d, d, 0, nullptr, 0, 0.f, 0, st));
         RC(lin_fwd(mem_, d, P(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, k.cv, d, (long long)B * K, d, d, 0, nullptr, 0, 0.f, 0, st));
         RC(cross_attn_fwd_launch(k.cq, k.ck, k.cv, k.cao, k.cP, B, T, K, d, NH, p, last_.seed, site + 2, st));
         RC(lin_fwd(k.cao, d, P(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, k.x2, d, BT, d, d, 0, k.x1, d, p, site + 3, st));
+        }
         // feed forward
         RC(layernorm_fwd_launch(k.x2, P(pre + "ffn_layer_norm.weight"), P(pre + "ffn_layer_norm.bias"), k.ln3, k.ln3_mean, k.ln3_rstd, BT, d, st));
         RC(lin_fwd(k.ln3, d, P(pre + "ffn.0.weight"), P(pre + "ffn.0.bias"), k.f1, 4 * d, BT, 4 * d, d, 1, nullptr, 0, 0.f, 0, st));
@@ -748,12 +783,36 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         // ---- cross attention
         RC(drop_gx(site + 3, q.gbr[1]));
         const float* gd_co = gd;
+        if (xattn_) {
+            // folded backward (xattn.hip): d probabilities, soft-max backward and d LN(x) in one launch; the per-image sums
+            // d Vo_b = Pd^T d out and d A_b = dS^T LN(x) are two batched products; a per-image kernel takes them back to the projection
+            // weights (partials summed over the images in a fixed order) and to d ck / d cv
+            const int NC = NH * xattn_kp(K, NH);
+            XaHost hx;
+            hx.x = k.ln2; hx.y = gt1_; hx.P = k.cP; hx.Ab = k.xaAb; hx.AbT = k.xaAbT; hx.Vo = k.xaVo; hx.VoT = k.xaVoT; hx.gd = gd_co; hx.Pd = xa_Pd_; hx.dS = xa_dS_;
+            hx.B = B; hx.T = T; hx.K = K; hx.d = d; hx.h = NH; hx.p = p; hx.seed = last_.seed; hx.site_p = site + 2; hx.site_o = site + 3;
+            RC(xattn_launch(hx, 1, st));                                                                                  // gt1 = d ln2
+            GemmArgs ga;
+            ga.M = NC; ga.N = d; ga.K = T; ga.lda = NC; ga.ldb = d; ga.ldc = d; ga.akc = 0; ga.bkc = 0; ga.batch = B;
+            ga.sA = (long long)T * NC; ga.sB = (long long)T * d; ga.sC = (long long)NC * d;
+            ga.A = xa_Pd_; ga.B = gd_co; ga.C = xa_dVo_;
+            RC(gemm_launch(ga, st));
+            ga.A = xa_dS_; ga.B = k.ln2; ga.C = xa_dAb_;
+            RC(gemm_launch(ga, st));
+            XaFoldBwdHost fb;
+            fb.dAb = xa_dAb_; fb.dVo = xa_dVo_; fb.ck = k.ck; fb.cv = k.cv; fb.Wq = P(pre + "encoder_decoder_attn.proj_q.weight"); fb.Wo = P(pre + "encoder_decoder_attn.proj_o.weight");
+            fb.dck = gck_; fb.dcv = gcv_; fb.dWq_part = xa_pq_; fb.dWo_part = xa_po_; fb.B = B; fb.K = K; fb.d = d; fb.h = NH;
+            RC(xattn_fold_bwd_launch(fb, st));
+            RC(colsum_launch(xa_pq_, (long long)d * d, G(pre + "encoder_decoder_attn.proj_q.weight"), B, d * d, 0, 1.f, scratch_, scratch_floats_, st));
+            RC(colsum_launch(xa_po_, (long long)d * d, G(pre + "encoder_decoder_attn.proj_o.weight"), B, d * d, 0, 1.f, scratch_, scratch_floats_, st));
+        } else {
         RC(lin_bwd_x(gd, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d cao
         RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, q.gt2, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, scratch_, scratch_floats_, st));   // gt2 = d cq
         RC(dw_sync());
         RC(dw(gd_co, d, k.cao, d, G(pre + "encoder_decoder_attn.proj_o.weight"), nullptr, BT, d, d));
         RC(dw(q.gt2, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d));
         RC(lin_bwd_x(q.gt2, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
+        }
         RC(lin_bwd_w(gck_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, BK, d, d, 1.f, st));
         RC(lin_bwd_w(gcv_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, BK, d, d, 1.f, st));
         RC(lin_bwd_x(gck_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, st));

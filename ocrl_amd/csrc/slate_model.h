@@ -142,7 +142,12 @@ private:
         float *ln1, *ln1_mean, *ln1_rstd, *q, *k, *v, *lse, *ao, *x1;
         float *ln2, *ln2_mean, *ln2_rstd, *cq, *ck, *cv, *cP, *cao, *x2;
         float *ln3, *ln3_mean, *ln3_rstd, *f1, *x3;
+        float *xaAb, *xaAbT, *xaVo, *xaVoT;       // folded cross-attention operands per image (xattn.hip): [B,NC,d], [B,d,NC], [B,NC,d], [B,d,NC]
     };
+    bool xattn_ = false;                  // OCRL_XATTN (default 1): cross attention in its folded form (one launch per block and direction)
+    float *xa_Pd_ = nullptr, *xa_dS_ = nullptr, *xa_dAb_ = nullptr, *xa_dVo_ = nullptr, *xa_pq_ = nullptr, *xa_po_ = nullptr;
+    size_t xa_zero_floats_ = 0;           // the per-block operand buffers form one contiguous region that bind() zeroes (padding columns)
+    float* xa_zero_base_ = nullptr;
     std::vector<Blk> blk_;
     // per-block gradient temporaries that a weight-gradient product on the side stream may still be reading while the main stream has
     // moved on: the dropout-backward copies of the residual gradient at the three branch outputs, d ffn-hidden, d cross-attention query,

@@ -583,7 +583,7 @@ __host__ __device__ inline size_t sa_xchg_floats(int K, int D) {
 }
 #define SA_TS 256        // streaming workgroup: 4 waves
 template <int K, bool V2>
-__global__ __launch_bounds__(SA_TS, 3) void sa_stream_fwd_kernel(SlotAttnArgs p, int t, int NS) {
+__global__ __launch_bounds__(SA_TS, V2 ? 4 : 3) void sa_stream_fwd_kernel(SlotAttnArgs p, int t, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int C = SA_C, KP = SaBlk<K>::KP;
     const int D = p.D, N = p.N, nt = blockDim.x, nw = nt >> 6, tid = threadIdx.x;
