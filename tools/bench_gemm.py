@@ -26,6 +26,14 @@ SHAPES = [  # (name, M, N, K, akc, bkc, splitk)
     ("dW TN 768x192x131072 s85", 768, 192, 131072, 0, 0, 85),
     ("dW TN 64x64x2097152 s1024", 64, 64, 2097152, 0, 0, 1024),
     ("dW TN 4096x192x131072 s16", 4096, 192, 131072, 0, 0, 16),
+    # the skinny weight gradients of the dVAE backward (side stream): decoder.9 [256,64] over 4BT rows, decoder.11 [4,64] over BN rows,
+    # encoder.7 [4096,64] over BT rows, the 64x64 layers over BT / 4BT rows
+    ("dvae dW TN 256x64x524288 s512", 256, 64, 524288, 0, 0, 512),
+    ("dvae dW TN 4x64x2097152 s512", 4, 64, 2097152, 0, 0, 512),
+    ("dvae dW TN 4096x64x131072 s32", 4096, 64, 131072, 0, 0, 32),
+    ("dvae dW TN 64x64x524288 s1024", 64, 64, 524288, 0, 0, 1024),
+    ("dvae dX NN 524288x64x256", 524288, 64, 256, 1, 0, 1),
+    ("dvae dX NN 131072x64x4096", 131072, 64, 4096, 1, 0, 1),
 ]
 only = sys.argv[1:] 
 for name, M, N, K, akc, bkc, sk in SHAPES:
