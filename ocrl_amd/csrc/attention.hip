@@ -12,6 +12,7 @@
 // One workgroup = 4 waves = 64 queries (or 64 keys); tiles of 64 keys (queries) stream through LDS.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define FA_BLK 64
 #ifndef FA_LPT
@@ -496,6 +497,186 @@ __global__ __launch_bounds__(256, FA_BWD_WGS) void attn_bwd_q_kernel(AttnArgs p)
     }
 }
 
+// ------------------------------------------------------------------------------------------- backward, one pass: dK, dV and dQ
+// One workgroup of 8 waves per (image, head) walks the causal triangle: key blocks of 128 (16 keys per wave) outermost, 64-query tiles
+// inside.  Per pair it computes S and dP once (the two-kernel form computes them twice: 7 product-equivalents, 5 here), accumulates
+// dK / dV of its keys in registers, and adds the pair's dQ contribution to the query tile in global memory: the workgroup is the only
+// writer of its (image, head)'s dQ, a thread always touches the same addresses of a tile, and the key blocks arrive in a fixed order, so
+// the read-modify-write needs no atomics and is bitwise reproducible.  For the dQ product the score gradients go through LDS once
+// ([64 queries][128 keys]); wave (qs, kh) takes 16 queries x 64 keys with its 64 keys' K rows held as B operands in registers, the upper
+// key half hands its partial to the lower one through LDS.  Every workgroup does the same work (no causal imbalance, no dispatch order
+// tricks); B * h workgroups.  Selected by OCRL_ATTN_BWD=1 (attn_launch).
+#define FB_KB 128
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
+    constexpr int NC = FaCfg<DH>::NC, LD = FaCfg<DH>::LD, SLD = FB_KB + 4;
+    __shared__ __attribute__((aligned(16))) float Qs[FA_BLK * LD];
+    __shared__ __attribute__((aligned(16))) float Gs[FA_BLK * LD];      // dO
+    __shared__ __attribute__((aligned(16))) float Ss[FA_BLK * SLD];     // dS [query][key of the block]
+    __shared__ __attribute__((aligned(16))) float Rs[4 * 16 * DH];      // dQ partials of the upper key half
+    __shared__ float Ls[FA_BLK], Ds[FA_BLK];
+    const int hd = blockIdx.x % p.h;
+    const long long b = blockIdx.x / p.h;
+    const int T = p.T, d = p.ld, hoff = hd * DH;
+    const long long bt0 = b * T;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int qs = wv & 3, kh = wv >> 2;
+    const float scale = rsqrtf((float)DH);
+    const long long bh = b * p.h + hd;
+    const uint32_t thr = drop_thresh(p.p);
+    const float dsc = p.p > 0.f ? 1.0f / (1.0f - p.p) : 1.f;
+    const int nqt = (T + FA_BLK - 1) / FA_BLK, nkb = (T + FB_KB - 1) / FB_KB;
+    constexpr int F4 = DH / 4;
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int k_abs = kb * FB_KB + wv * 16 + li;                       // this lane's key (column of S)
+        float4 kf[NC], vf[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            kf[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vf[c] = kf[c];
+            if (k_abs < T) {
+                kf[c] = *reinterpret_cast<const float4*>(p.k + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g);
+                vf[c] = *reinterpret_cast<const float4*>(p.v + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g);
+            }
+        }
+        // B operands of the dQ product: step (j, e) of lane group g uses key kh*64 + 16 j + 4 g + e, column = head dimension 16 c + li
+        float kq[16][NC];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int key = kb * FB_KB + kh * 64 + 16 * (s >> 2) + 4 * g + (s & 3);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kq[s][c] = key < T ? p.k[(bt0 + key) * d + hoff + 16 * c + li] * scale : 0.f;
+        }
+        f32x4_t dk[NC], dv[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { dk[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[c] = dk[c]; }
+#pragma unroll 1
+        for (int qt = (kb * FB_KB) / FA_BLK; qt < nqt; ++qt) {
+            __syncthreads();                                  // the previous pair is done with Qs / Gs / Ss / Rs
+            for (int idx = tid; idx < FA_BLK * F4; idx += 512) {
+                const int c4 = idx % F4, r = idx / F4;
+                float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = q4;
+                if (qt * FA_BLK + r < T) {
+                    q4 = *reinterpret_cast<const float4*>(p.q + (bt0 + qt * FA_BLK + r) * d + hoff + c4 * 4);
+                    g4 = *reinterpret_cast<const float4*>(p.dO + (bt0 + qt * FA_BLK + r) * p.d + hoff + c4 * 4);
+                }
+                *reinterpret_cast<float4*>(Qs + r * LD + c4 * 4) = make_float4(q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale);
+                *reinterpret_cast<float4*>(Gs + r * LD + c4 * 4) = g4;
+            }
+            if (tid < FA_BLK) {
+                const int qq = qt * FA_BLK + tid;
+                Ls[tid] = qq < T ? p.lse[bh * T + qq] : 0.f;
+                Ds[tid] = qq < T ? p.delta[bh * T + qq] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+                f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float4 a = *reinterpret_cast<const float4*>(Qs + (16 * sq + li) * LD + 16 * c + 4 * g);
+                    s = MFMA16(a.x, kf[c].x, s);
+                    s = MFMA16(a.y, kf[c].y, s);
+                    s = MFMA16(a.z, kf[c].z, s);
+                    s = MFMA16(a.w, kf[c].w, s);
+                    const float4 e = *reinterpret_cast<const float4*>(Gs + (16 * sq + li) * LD + 16 * c + 4 * g);
+                    dp = MFMA16(e.x, vf[c].x, dp);
+                    dp = MFMA16(e.y, vf[c].y, dp);
+                    dp = MFMA16(e.z, vf[c].z, dp);
+                    dp = MFMA16(e.w, vf[c].w, dp);
+                }
+                uint2 hb = make_uint2(0u, 0u);
+                if (p.p > 0.f) {
+                    const int qh = qt * FA_BLK + 16 * sq + 4 * g + (li & 3);
+                    const uint64_t idx = ((uint64_t)bh * T + (uint64_t)(qh < T ? qh : 0)) * T + (uint64_t)(k_abs < T ? k_abs : 0);
+                    hb = rng_bits4(p.seed, p.site, idx >> 2);
+                }
+                uint2 hq[4];
+                hq[0] = make_uint2(__builtin_amdgcn_update_dpp(0, (int)hb.x, 0x00, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, (int)hb.y, 0x00, 0xF, 0xF, false));
+                hq[1] = make_uint2(__builtin_amdgcn_update_dpp(0, (int)hb.x, 0x55, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, (int)hb.y, 0x55, 0xF, 0xF, false));
+                hq[2] = make_uint2(__builtin_amdgcn_update_dpp(0, (int)hb.x, 0xAA, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, (int)hb.y, 0xAA, 0xF, 0xF, false));
+                hq[3] = make_uint2(__builtin_amdgcn_update_dpp(0, (int)hb.x, 0xFF, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, (int)hb.y, 0xFF, 0xF, 0xF, false));
+                f32x4_t pd, ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = 16 * sq + 4 * g + r;
+                    const int qa = qt * FA_BLK + ql;
+                    float pr = 0.f;
+                    if (qa < T && k_abs <= qa && k_abs < T) pr = __expf(s[r] - Ls[ql]);
+                    float keep = 1.f;
+                    if (p.p > 0.f) keep = rng_keep(hq[r], li & 3, thr) ? dsc : 0.f;
+                    pd[r] = pr * keep;
+                    ds[r] = pr * (dp[r] * keep - Ds[ql]);
+                    Ss[ql * SLD + wv * 16 + li] = ds[r];
+                }
+                float ag[4][NC], aq[4][NC];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        ag[r][c] = Gs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
+                        aq[r][c] = Qs[(16 * sq + 4 * g + r) * LD + 16 * c + li];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        dv[c] = MFMA16(ag[r][c], pd[r], dv[c]);
+                        dk[c] = MFMA16(aq[r][c], ds[r], dk[c]);
+                    }
+            }
+            __syncthreads();                                  // dS of the pair is complete
+            // ---- dQ[16 queries of qs][DH] over this wave's 64 keys: A = dS[q][key] (four consecutive keys per ds_read_b128), B = kq
+            f32x4_t dq[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dq[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a4 = *reinterpret_cast<const float4*>(Ss + (16 * qs + li) * SLD + kh * 64 + 16 * j + 4 * g);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    dq[c] = MFMA16(a4.x, kq[4 * j + 0][c], dq[c]);
+                    dq[c] = MFMA16(a4.y, kq[4 * j + 1][c], dq[c]);
+                    dq[c] = MFMA16(a4.z, kq[4 * j + 2][c], dq[c]);
+                    dq[c] = MFMA16(a4.w, kq[4 * j + 3][c], dq[c]);
+                }
+            }
+            // dq[c][r] = dQ[query 16 qs + 4 g + r][dimension 16 c + li]
+            if (kh == 1) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Rs[(qs * 16 + 4 * g + r) * DH + 16 * c + li] = dq[c][r];
+            }
+            __syncthreads();
+            if (kh == 0) {
+                const bool first = kb == 0;                    // key block 0 meets every query tile first: it initialises dQ
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qa = qt * FA_BLK + 16 * qs + 4 * g + r;
+                    if (qa >= T) continue;
+                    float* dst = p.dq + (bt0 + qa) * d + hoff + li;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const float v = dq[c][r] + Rs[(qs * 16 + 4 * g + r) * DH + 16 * c + li];
+                        dst[16 * c] = first ? v : dst[16 * c] + v;
+                    }
+                }
+            }
+        }
+        if (k_abs < T) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                *reinterpret_cast<float4*>(p.dv + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g) = make_float4(dv[c][0], dv[c][1], dv[c][2], dv[c][3]);
+                *reinterpret_cast<float4*>(p.dk + (bt0 + k_abs) * d + hoff + 16 * c + 4 * g) = make_float4(dk[c][0], dk[c][1], dk[c][2], dk[c][3]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- launchers
 template <int DH>
 static int attn_launch_dh(const AttnArgs& a, int mode, hipStream_t st) {
@@ -509,10 +690,19 @@ static int attn_launch_dh(const AttnArgs& a, int mode, hipStream_t st) {
         OCRL_REQUIRE(a.d % 4 == 0 && a.d <= 1024 && (a.d / 4) % a.h == 0, "attention: d must be a multiple of 4*h, <= 1024");
         hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(BT, 256 / (a.d / 4))), dim3(256), 0, st, a.dO, a.o, a.delta, BT, a.T, a.d, a.h);
         OCRL_CHECK_LAUNCH("attn_delta");
+        // OCRL_ATTN_BWD=1 selects the one-pass form (5 instead of 7 product-equivalents); default: the two-kernel form
+        // (measured at B = 128, T = 1024, 4 heads of 48: 2.21 ms against 2.11 ms -- 222 registers leave one 8-wave workgroup per CU, and
+        // what the two products save is lost to the lower occupancy; kept as a tested alternative, not the default)
+        const char* fe = getenv("OCRL_ATTN_BWD");
+        if (fe && atoi(fe) == 1) {
+            hipLaunchKernelGGL((attn_bwd_fused_kernel<DH>), dim3(a.B * a.h), dim3(512), 0, st, a);
+            OCRL_CHECK_LAUNCH("attn_bwd_fused");
+        } else {
         hipLaunchKernelGGL((attn_bwd_kv_kernel<DH>), grid, blk, 0, st, a);
         OCRL_CHECK_LAUNCH("attn_bwd_kv");
         hipLaunchKernelGGL((attn_bwd_q_kernel<DH>), grid, blk, 0, st, a);
         OCRL_CHECK_LAUNCH("attn_bwd_q");
+        }
     }
     return 0;
 }

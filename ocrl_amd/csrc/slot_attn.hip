@@ -1027,21 +1027,25 @@ size_t sa_xchg_floats_host(int K, int D) {
 // partial sums of the streaming launches: one [K][65] block per streaming workgroup; B * NS <= SA_MAX_BLOCKS + B by construction
 size_t sa_parts_floats_host(int B, int K) { return (size_t)(SA_MAX_BLOCKS + B) * K * (SA_C + 1); }
 
-// streaming workgroups per image: fill every CU several workgroups deep, at least 8 tiles of 16 positions per workgroup (2 per wave)
-static int sa_splits(int B, int N) {
+// streaming workgroups per image: `per_cu` workgroups per CU in total, so that a launch is a whole number of resident rounds (a launch
+// bound of 3 with 4 workgroups per CU ran one full round and a second one a third full: the round-2 forward); at least 8 tiles of 16
+// positions per workgroup (2 per wave)
+static int sa_splits(int B, int N, int per_cu) {
     static int ncu = 0, mult = 0;
     if (!ncu) {
         int dev = 0;
         hipDeviceProp_t prop;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-        const char* e = getenv("OCRL_SA_WGS");          // streaming workgroups per CU per launch (development knob)
-        mult = e ? atoi(e) : 4;
-        if (mult < 1) mult = 1;
+        const char* e = getenv("OCRL_SA_WGS");          // streaming workgroups per CU per launch (development knob; 0 = the kernel's own)
+        mult = e ? atoi(e) : 0;
     }
     const int ntile = (N + 15) / 16;
-    int target = mult * ncu;
+    int target = (mult > 0 ? mult : per_cu) * ncu;
     if (target > SA_MAX_BLOCKS) target = SA_MAX_BLOCKS;
-    int ns = (target + B - 1) / B;
+    int ns = B <= target ? target / B : 1;              // rounded down: never more workgroups than one full round
+    // OCRL_SA_NS (read at every call): a fixed split count, so that a small batch groups its partial sums exactly like a large one --
+    // tests/test_gpu_benchshape.py compares a B = 128 step with a B = 1 step of the same image bit for bit
+    if (const char* f = getenv("OCRL_SA_NS")) { const int v = atoi(f); if (v > 0 && (long long)B * v <= SA_MAX_BLOCKS) ns = v; }
     if (ns > ntile / 8) ns = ntile / 8;
     return ns < 1 ? 1 : ns;
 }
@@ -1064,12 +1068,13 @@ static int sa_launch_kg(const SlotAttnArgs& a, int backward, hipStream_t st) {
         OCRL_HIP(hipFuncSetAttribute((const void*)sa_slot_bwd_kernel<K, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_b = smem;
     }
-    const int NS = sa_splits(a.B, a.N);
+    static int fwd_form = -1;          // OCRL_SA_FWD=1: the round-2 streaming forward (slots on the lanes); default: positions on the lanes
+    if (fwd_form < 0) { const char* e = getenv("OCRL_SA_FWD"); fwd_form = e ? atoi(e) : 2; }
+    // resident streaming workgroups per CU (launch bounds): forward 4 (3 for the round-2 form), backward 2 -- the backward runs two rounds
+    const int NS = sa_splits(a.B, a.N, backward ? 4 : (fwd_form == 1 ? 3 : 4));
     const int ngrp = (a.B + G - 1) / G;
     const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
     if (!backward) {
-        static int fwd_form = -1;          // OCRL_SA_FWD=1: the round-2 streaming forward (slots on the lanes); default: positions on the lanes
-        if (fwd_form < 0) { const char* e = getenv("OCRL_SA_FWD"); fwd_form = e ? atoi(e) : 2; }
         const size_t smem_stream = (size_t)(KP * SA_C + 16 + (SA_TS / 64) * (16 * SA_TLD + 16 * SA_WT_LD)) * 4;
         if (a.phase != 2) hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
         for (int t = 0; t < a.I && a.phase != 1; ++t) {

@@ -54,8 +54,11 @@ def _acts_image0(eng, cfg, nb):
 
 
 @pytest.mark.parametrize("tag,over", CONFIGS)
-def test_replicated_image_equals_single_image_engine(tag, over):
+def test_replicated_image_equals_single_image_engine(tag, over, monkeypatch):
     from ocrl_amd.engine import SlateEngine
+    # the slot-attention streaming launches cut an image into B-dependent many partial sums (8 per image at B = 128, 128 at B = 1); with the
+    # count pinned, every per-image quantity of the forward is computed by the same arithmetic at both batch sizes and must agree bit for bit
+    monkeypatch.setenv("OCRL_SA_NS", "8")
     cfg = O.default_cfg(**over)
     _need(cfg, 120 if cfg.obs_size == 256 else 50)
     S, E = cfg.obs_size, cfg.obs_size // 4
@@ -101,9 +104,7 @@ def test_replicated_image_equals_single_image_engine(tag, over):
     same = all(torch.equal(rep[k][0], rep[k][B - 1]) for k in ("slots", "attn", "recon", "dec_out"))
     log(f"[{tag}] replicated image vs B=1 engine: " + " ".join(f"{k}={v:.2e}" for k, v in worst.items()) + f"; image 0 == image {B - 1} bitwise: {same}")
     for k, v in worst.items():
-        # rounding only (measured 1.0e-6 on attn): the slot-attention partial sums are grouped differently at B = 1 (128 partials per image)
-        # and at B = 128 (8 per image); image 0 and image 127 of the batch agree bit for bit
-        assert v < 5e-6, (k, v)
+        assert v == 0.0, (k, v)          # bitwise: no kernel's per-image arithmetic depends on the batch size or on the image's place in the batch
     # every image of the batch, against image 0 (cheap: on the tensors already on the host)
     for k in ("slots", "recon"):
         spread = (rep[k] - rep[k][:1]).abs().max().item() / rep[k][0].abs().max().item()
