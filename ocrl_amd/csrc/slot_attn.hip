@@ -778,6 +778,180 @@ __device__ __forceinline__ void sa_stream_bwd(const float4* __restrict__ xb, flo
     }
 }
 
+// ------------------------------------------------------------------------------------------- backward streaming pass, second form
+// The transposed form of sa_stream_fwd2 applied to the backward: logits^T and (d attn)^T arrive with the position on the lane and four
+// slots in the registers, so the soft-max recomputation, its backward and the weights are in-lane arithmetic plus cross-row exchanges;
+// d xn^T[ch][pos] = dug^T wn^T + qg^T dl^T contracts over the slots with wn / dl straight from those registers as B operands and lands
+// in the load layout of x (no LDS transposition of the 16 x 64 result); only sum_n dl xn^T needs dl through the 16 x 16 LDS patch.
+template <int K, bool FIRST, bool FINAL>
+__device__ __forceinline__ void sa_stream_bwd2(const float4* __restrict__ xb, float4* __restrict__ dxb, int N, const float* qg, const float* qb,
+                                               const float* dug, const float* dub, const float* cs, const float* ud, float eps, float* tiles,
+                                               float* scr, int tile0, int tile1) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, li = lane & 15, g = lane >> 4;
+    float* tile = tiles + wv * (16 * SA_TLD + 2 * 16 * SA_WLD);
+    float* wt = tile + 16 * SA_TLD;                      // [16 slots][SA_WT_LD] (the region of the first form's two [16][17] patches)
+    float qpr[16], dur[16];                              // A operands of the two [slot][pos] products: lane (slot li, channel group g)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int ch = 16 * (k >> 2) + 4 * g + (k & 3);
+        qpr[k] = li < K ? qg[li * SA_C + ch] * SA_LOG2E : 0.f;
+        dur[k] = li < K ? dug[li * SA_C + ch] : 0.f;
+    }
+    float duA[4][4], qgA[4][4];                          // A operands of d xn^T: [channel 16 m + li][slot 4 g + r]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int slot = 4 * g + r;
+            duA[m][r] = slot < K ? dug[slot * SA_C + 16 * m + li] : 0.f;
+            qgA[m][r] = slot < K ? qg[slot * SA_C + 16 * m + li] : 0.f;
+        }
+    float qbr[4], dbr[4], icr[4];                        // per-slot constants of this lane's four slots
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int slot = 4 * g + r;
+        qbr[r] = slot < K ? qb[slot] * SA_LOG2E : -1e30f;
+        icr[r] = slot < K ? 1.0f / cs[slot] : 0.f;
+        dbr[r] = slot < K ? dub[slot] - ud[slot] : 0.f;
+    }
+    f32x4_t acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float sdl[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ntile = tile1;
+    float4 cur[4];
+    if (tile0 + wv < ntile) sa_load_tile(xb, N, tile0 + wv, li, g, cur);
+#pragma unroll 1
+    for (int t = tile0 + wv; t < ntile; t += nw) {
+        float4 nxt[4];
+        if (t + nw < ntile) sa_load_tile(xb, N, t + nw, li, g, nxt);
+        const int pos = t * 16 + li;
+        float4 od[4];
+        if (!FIRST) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) od[c] = pos < N ? dxb[pos * 16 + 4 * c + g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // ---- LayerNorm statistics, centred x
+        f32x2_t v2[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v2[2 * c] = (f32x2_t){cur[c].x, cur[c].y}; v2[2 * c + 1] = (f32x2_t){cur[c].z, cur[c].w}; }
+        f32x2_t s2 = ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
+        const float mu = sa_xrow_sum4(s2.x + s2.y) * (1.0f / SA_C);
+        const f32x2_t mu2 = (f32x2_t){mu, mu};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v2[k] -= mu2;
+        f32x2_t q2 = v2[0] * v2[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) q2 = __builtin_elementwise_fma(v2[k], v2[k], q2);
+        const float rs = __builtin_amdgcn_rsqf(sa_xrow_sum4(q2.x + q2.y) * (1.0f / SA_C) + 1e-5f);
+        // ---- logits^T and (d attn)^T: four independent chains
+        f32x4_t La = (f32x4_t){0.f, 0.f, 0.f, 0.f}, Lb = La, Da = La, Db = La;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            La = MFMA16(qpr[2 * k], v2[k].x, La);
+            Da = MFMA16(dur[2 * k], v2[k].x, Da);
+            Lb = MFMA16(qpr[2 * k + 1], v2[k].y, Lb);
+            Db = MFMA16(dur[2 * k + 1], v2[k].y, Db);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<float4*>(tile + li * SA_TLD + 16 * c + 4 * g) = make_float4(v2[2 * c].x, v2[2 * c].y, v2[2 * c + 1].x, v2[2 * c + 1].y);
+        // ---- soft-max of position li, its backward, the normalised weights
+        float l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) l[r] = __builtin_fmaf(La[r] + Lb[r], rs, qbr[r]);
+        float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+        mx = sa_xrow16(mx, true);
+        if (K > 8) mx = sa_xrow32(mx, true);
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = __builtin_amdgcn_exp2f(l[r] - mx);
+        float sm = (a[0] + a[1]) + (a[2] + a[3]);
+        sm = sa_xrow16(sm, false);
+        if (K > 8) sm = sa_xrow32(sm, false);
+        const float inv = __builtin_amdgcn_rcpf(sm);
+        float da[4], dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[r] *= inv;
+            da[r] = (__builtin_fmaf(Da[r] + Db[r], rs, dbr[r])) * icr[r];          // d attn[pos][slot] (0 for padded slots: icr = 0)
+            dot = __builtin_fmaf(a[r], da[r], dot);
+        }
+        dot = sa_xrow16(dot, false);
+        if (K > 8) dot = sa_xrow32(dot, false);
+        const float live = pos < N ? 1.f : 0.f;
+        float dl[4], wn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dl[r] = a[r] * (da[r] - dot) * live;                 // d logits
+            wn[r] = (a[r] + eps) * icr[r] * live;                // normalised weight
+            sdl[r] += dl[r];
+            wt[(4 * g + r) * SA_WT_LD + li] = dl[r] * rs;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float4 wb4 = *reinterpret_cast<const float4*>(wt + li * SA_WT_LD + 4 * g);      // dl rstd of slot li at positions 4g .. 4g+3
+        const float wb[4] = {wb4.x, wb4.y, wb4.z, wb4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = MFMA16(tile[(4 * g + r) * SA_TLD + 16 * m + li], wb[r], acc[m]);   // sum_n dl xn^T: [ch][slot]
+        // ---- d xn^T[ch][pos] = sum_slot dug[slot][ch] wn[pos][slot] + qg[slot][ch] dl[pos][slot]
+        f32x4_t Dx[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Dx[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                Dx[m] = MFMA16(duA[m][r], wn[r], Dx[m]);
+                Dx[m] = MFMA16(qgA[m][r], dl[r], Dx[m]);
+            }
+        __builtin_amdgcn_wave_barrier();          // the tile and the patch may be overwritten by the next step
+        float dv[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { dv[4 * m] = Dx[m][0]; dv[4 * m + 1] = Dx[m][1]; dv[4 * m + 2] = Dx[m][2]; dv[4 * m + 3] = Dx[m][3]; }
+        if (!FIRST) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { dv[4 * c] += od[c].x; dv[4 * c + 1] += od[c].y; dv[4 * c + 2] += od[c].z; dv[4 * c + 3] += od[c].w; }
+        }
+        if (FINAL) {      // LayerNorm(norm_inputs) backward from d xn, in the load layout (xn = centred x * rstd)
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                m1 += dv[2 * k] + dv[2 * k + 1];
+                m2 += dv[2 * k] * v2[k].x + dv[2 * k + 1] * v2[k].y;
+            }
+            m1 = sa_xrow_sum4(m1) * (1.0f / SA_C);
+            m2 = sa_xrow_sum4(m2) * rs * (1.0f / SA_C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                dv[2 * k] = rs * (dv[2 * k] - m1 - v2[k].x * rs * m2);
+                dv[2 * k + 1] = rs * (dv[2 * k + 1] - m1 - v2[k].y * rs * m2);
+            }
+        }
+        if (pos < N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dxb[pos * 16 + 4 * c + g] = make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdl[r] = red16_sum(sdl[r]);
+    __syncthreads();
+    if (li < K) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scr[(wv * K + li) * (SA_C + 1) + 16 * m + 4 * g + r] = acc[m][r];
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < K) scr[(wv * K + 4 * g + r) * (SA_C + 1) + SA_C] = sdl[r];
+    }
+}
+
 // LDS map of the backward slot-side kernel
 template <int K, int G>
 struct SaBwdLds {
@@ -982,7 +1156,7 @@ __global__ __launch_bounds__(SA_TB) void sa_slot_bwd_kernel(SlotAttnArgs p, SaWt
     for (int i = tid; i < (nimg - 1) * SM; i += nt) gs[SM + i] = 0.f;
 }
 // 2 workgroups per CU = 256 VGPRs: at 3 (170 VGPRs) the FINAL variant spills 12 registers and the backward chain is 86 us slower
-template <int K, bool FIRST, bool FINAL>
+template <int K, bool FIRST, bool FINAL, bool V2>
 __global__ __launch_bounds__(SA_TS, 2) void sa_stream_bwd_kernel(SlotAttnArgs p, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int C = SA_C, KP = SaBlk<K>::KP;
@@ -1001,7 +1175,8 @@ __global__ __launch_bounds__(SA_TS, 2) void sa_stream_bwd_kernel(SlotAttnArgs p,
     float4* dxb = reinterpret_cast<float4*>(p.dx + (size_t)b * N * C);
     const int ntile = (N + 15) / 16, per = (ntile + NS - 1) / NS;
     const int t0 = h * per, t1 = (t0 + per < ntile) ? t0 + per : ntile;
-    sa_stream_bwd<K, FIRST, FINAL>(xb, dxb, N, qg, sv4, dug, sv4 + 16, sv4 + 32, sv4 + 48, p.eps, tiles, tiles, t0, t1 > t0 ? t1 : t0);
+    if (V2) sa_stream_bwd2<K, FIRST, FINAL>(xb, dxb, N, qg, sv4, dug, sv4 + 16, sv4 + 32, sv4 + 48, p.eps, tiles, tiles, t0, t1 > t0 ? t1 : t0);
+    else sa_stream_bwd<K, FIRST, FINAL>(xb, dxb, N, qg, sv4, dug, sv4 + 16, sv4 + 32, sv4 + 48, p.eps, tiles, tiles, t0, t1 > t0 ? t1 : t0);
     __syncthreads();
     float* part = p.parts + ((size_t)b * NS + h) * K * (C + 1);
     for (int i = tid; i < K * (C + 1); i += nt) {
@@ -1083,14 +1258,24 @@ static int sa_launch_kg(const SlotAttnArgs& a, int backward, hipStream_t st) {
             hipLaunchKernelGGL((sa_slot_fwd_kernel<K, G>), dim3(ngrp), dim3(SA_TF), smem, st, a, wo, so, t, NS);
         }
     } else {
+        static int bwd_form = -1;          // OCRL_SA_BWD=1: the round-2 streaming backward; default: positions on the lanes
+        if (bwd_form < 0) { const char* e = getenv("OCRL_SA_BWD"); bwd_form = e ? atoi(e) : 2; }
+        static_assert(16 * SA_WT_LD <= 2 * 16 * SA_WLD, "the weight patch of the second form must fit the first form's two patches");
         const size_t smem_stream = (size_t)(2 * KP * SA_C + 64 + (SA_TS / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD)) * 4;
         hipLaunchKernelGGL((sa_slot_bwd_kernel<K, G>), dim3(ngrp), dim3(SA_TB), smem, st, a, wo, so, go, -1, a.I - 1, NS);
         for (int t = a.I - 1; t >= 0; --t) {
             const bool first = (t == a.I - 1), final_ = (t == 0);
-            if (first && final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
-            else if (first) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
-            else if (final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
-            else hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            if (bwd_form == 1) {
+                if (first && final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, true, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+                else if (first) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, false, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+                else if (final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, true, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+                else hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, false, false>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            } else {
+                if (first && final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, true, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+                else if (first) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, true, false, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+                else if (final_) hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, true, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+                else hipLaunchKernelGGL((sa_stream_bwd_kernel<K, false, false, true>), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            }
             hipLaunchKernelGGL((sa_slot_bwd_kernel<K, G>), dim3(ngrp), dim3(SA_TB), smem, st, a, wo, so, go, t, t - 1, NS);
         }
     }
