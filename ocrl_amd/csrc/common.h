@@ -71,6 +71,10 @@ __host__ __device__ inline uint2 rng_bits4_keyed(uint32_t key, uint32_t idx4_lo)
     const uint32_t k2 = key * 0x9E3779B9u + 0x7F4A7C15u;      // uniform over a launch: scalar work
     return make_uint2(rng_mix32k(c, k2), rng_mix32k(c ^ 0x68E31DA4u, k2) + key);
 }
+// the first word alone (callers that need one uniform per counter)
+__host__ __device__ inline uint32_t rng_bits1_keyed(uint32_t key, uint32_t idx_lo) {
+    return rng_mix32k(idx_lo ^ key, key * 0x9E3779B9u + 0x7F4A7C15u);
+}
 __host__ __device__ inline uint2 rng_bits4(uint64_t seed, uint32_t site, uint64_t idx4) {
     return rng_bits4_keyed(rng_key(seed, site, (uint32_t)(idx4 >> 32)), (uint32_t)idx4);
 }

@@ -512,10 +512,23 @@ __global__ __launch_bounds__(256) void ce_kernel(float* __restrict__ pred, const
 // One wave per row, lane = 64-column segment: combines the per-segment (max, sum-exp) pairs the GEMM epilogue left in `stat` into
 // lse[row]; optionally picks the hard Gumbel sample (first maximum over the segment maxima -> tokens[row]) and the cross-entropy term
 // lse - pred[row, tok[row]], summed per block (16 rows, fixed order) into part[block].
+// hard sample by inverse CDF (device-RNG mode of the Gumbel head, gemm_impl.h epi_mode 2): hstat / hidx hold the per-segment
+// (max l, sum exp(l - max)) of the logits l; the token is a draw from Categorical(soft-max(l)) -- first the segment (cumulative segment
+// masses against one uniform of the row), then the entry inside it (a second uniform against the cumulative exp(l - max) of its 64
+// entries, l recovered from the stored scores: l = tau * y - g1 with g1 regenerated from the counter RNG exactly as the epilogue drew it)
+struct CdfArgs { const float* scores; int V; float tau; unsigned long long seed; };
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
 __global__ __launch_bounds__(1024) void softmax_stat_combine_kernel(const float* __restrict__ stat, int nseg, long long R, float* __restrict__ lse,
                                                                     const float* __restrict__ hstat, const int* __restrict__ hidx,
                                                                     int* __restrict__ tokens, const float* __restrict__ pred, int ldp,
-                                                                    const int* __restrict__ tok, float* __restrict__ part) {
+                                                                    const int* __restrict__ tok, float* __restrict__ part, CdfArgs cdf) {
     __shared__ float red[16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 16 + wave;
@@ -531,7 +544,38 @@ __global__ __launch_bounds__(1024) void softmax_stat_combine_kernel(const float*
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
         const float l = mx + __logf(t);
         if (lane == 0) lse[row] = l;
-        if (hstat) {
+        if (hstat && cdf.scores) {
+            float hm = -INFINITY, hsum = 0.f;
+            if (lane < nseg) { hm = hstat[(size_t)row * nseg + lane]; hsum = __builtin_bit_cast(float, hidx[(size_t)row * nseg + lane]); }
+            float M = hm;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+            const float w = hm > -INFINITY ? hsum * __expf(hm - M) : 0.f;
+            const float cw = wave_incl_scan(w, lane);
+            const float tot = __shfl(cw, 63, 64);
+            const uint2 ub = rng_bits4(cdf.seed, SITE_GUMBEL_ZH, (uint64_t)row);
+            const float target = u01_24(ub.x) * tot;
+            int js = __popcll(__ballot(cw < target));              // segments whose cumulative mass stays below the target
+            if (js > nseg - 1) js = nseg - 1;
+            const float hmj = __shfl(hm, js, 64);
+            // inside segment js: entry v = lane
+            const int col = js * 64 + lane;
+            float q = 0.f;
+            if (col < cdf.V) {
+                const uint64_t idx = (uint64_t)row * (uint64_t)cdf.V + col;
+                const uint32_t key = rng_key(cdf.seed, SITE_GUMBEL_Z, (uint32_t)(idx >> 32));
+                const float la = __logf(1.17549435e-38f - __logf(u01_24(rng_bits1_keyed(key, (uint32_t)idx))));
+                const float l = cdf.scores[idx] * cdf.tau + la;
+                q = __expf(l - hmj);
+            }
+            const float cq = wave_incl_scan(q, lane);
+            const float tq = __shfl(cq, 63, 64);
+            const float t2 = u01_24(ub.y) * tq;
+            int vs = __popcll(__ballot(cq < t2));
+            const int vmax = (cdf.V - js * 64) < 64 ? (cdf.V - js * 64) - 1 : 63;
+            if (vs > vmax) vs = vmax;
+            if (lane == 0) tokens[row] = js * 64 + vs;
+        } else if (hstat) {
             float b = -INFINITY;
             int bi = 0x7fffffff;
             if (lane < nseg) { b = hstat[(size_t)row * nseg + lane]; bi = hidx[(size_t)row * nseg + lane]; }
@@ -1389,12 +1433,16 @@ int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, in
 }
 // lse [R]; tokens (with hstat / hidx) and the cross-entropy sum (with pred / tok; out[0] = scale * sum, ws >= ceil(R/16) floats) are optional
 int softmax_stat_combine_launch(const float* stat, int nseg, long long R, float* lse, const float* hstat, const int* hidx, int* tokens,
-                                const float* pred, int ldp, const int* tok, float* out, float scale, float* ws, size_t ws_floats, hipStream_t st) {
+                                const float* pred, int ldp, const int* tok, float* out, float scale, float* ws, size_t ws_floats, hipStream_t st,
+                                const float* cdf_scores, int cdf_V, float cdf_tau, unsigned long long cdf_seed) {
     OCRL_REQUIRE(nseg >= 1 && nseg <= 64, "softmax_stat_combine: 1..64 segments (got %d)", nseg);
     const long long nblk = (R + 15) / 16;
     OCRL_REQUIRE(!pred || (tok && out && ws && ws_floats >= (size_t)nblk), "softmax_stat_combine: cross-entropy needs tokens, an output and %lld workspace floats", nblk);
+    CdfArgs cdf;
+    cdf.scores = cdf_scores; cdf.V = cdf_V; cdf.tau = cdf_tau; cdf.seed = cdf_seed;
+    OCRL_REQUIRE(!cdf_scores || (hstat && hidx && tokens && cdf_V > 0 && cdf_V <= nseg * 64), "softmax_stat_combine: inverse-CDF sampling arguments");
     hipLaunchKernelGGL(softmax_stat_combine_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, stat, nseg, R, lse, hstat, hidx, tokens, pred, ldp, tok,
-                       pred ? ws : nullptr);
+                       pred ? ws : nullptr, cdf);
     OCRL_CHECK_LAUNCH("softmax_stat_combine");
     if (pred) return reduce_partials_launch(ws, (int)nblk, out, scale, 0, st);
     return 0;

@@ -344,11 +344,11 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
         const int nseg = 2 * nbn, seg = 2 * bn + (wave & 1);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float sm[4], ss[4], hb[4], rl[4], rv[4];
+            float sm[4], ss[4], hb[4], hs[4], rl[4], rv[4];
             int hi[4];
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
-                sm[ps] = -INFINITY; ss[ps] = 0.f; hb[ps] = -INFINITY; hi[ps] = 0; rl[ps] = 0.f; rv[ps] = 0.f;
+                sm[ps] = -INFINITY; ss[ps] = 0.f; hb[ps] = -INFINITY; hs[ps] = 0.f; hi[ps] = 0; rl[ps] = 0.f; rv[ps] = 0.f;
                 const int row = m0 + wm0 + i * 32 + ps * 8 + rr0;
                 if (EPI == 3 && row < p.M) { rl[ps] = p.e_lse[row]; rv[ps] = p.e_rowvec[row]; }
             }
@@ -378,29 +378,16 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                         continue;
                     }
                     v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (EPI == 2) {
-                        float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la;      // log(E + tiny) of the two draws: g = -log(E + tiny)
+                    if (EPI == 2 && p.e1) {
+                        // injected Exp(1) noise (parity runs): both Gumbel samples exactly as the reference forms them,
+                        // g = -log(E + tiny); the hard sample is the first maximum of l + g2 (the factor 1/tau > 0 does not move it)
+                        float4 la = make_float4(0.f, 0.f, 0.f, 0.f), lb = la;
                         if (ok) {
                             const uint64_t idx = (uint64_t)row * (uint64_t)p.N + col;
-                            if (p.e1) {
-                                const float4 ea = *reinterpret_cast<const float4*>(p.e1 + idx), eb = *reinterpret_cast<const float4*>(p.e2 + idx);
-                                la = make_float4(__logf(ea.x + TINYF_G), __logf(ea.y + TINYF_G), __logf(ea.z + TINYF_G), __logf(ea.w + TINYF_G));
-                                lb = make_float4(__logf(eb.x + TINYF_G), __logf(eb.y + TINYF_G), __logf(eb.z + TINYF_G), __logf(eb.w + TINYF_G));
-                            } else {
-                                // the draws of gumbel_softmax_kernel (rng_bits4 at the element index), with the key taken once per four
-                                // elements.  The + tiny guard is live: the largest 24-bit uniform rounds to 1.0f, E = -log(1) = 0 (about 64 of
-                                // the 10^9 draws of a step at B = 128)
-                                const uint32_t key = rng_key(p.e_seed, SITE_GUMBEL_Z, (uint32_t)(idx >> 32)), lo = (uint32_t)idx;
-                                const uint2 b0 = rng_bits4_keyed(key, lo), b1 = rng_bits4_keyed(key, lo + 1), b2 = rng_bits4_keyed(key, lo + 2),
-                                            b3 = rng_bits4_keyed(key, lo + 3);
-                                la = make_float4(__logf(TINYF_G - __logf(u01_24(b0.x))), __logf(TINYF_G - __logf(u01_24(b1.x))),
-                                                 __logf(TINYF_G - __logf(u01_24(b2.x))), __logf(TINYF_G - __logf(u01_24(b3.x))));
-                                lb = make_float4(__logf(TINYF_G - __logf(u01_24(b0.y))), __logf(TINYF_G - __logf(u01_24(b1.y))),
-                                                 __logf(TINYF_G - __logf(u01_24(b2.y))), __logf(TINYF_G - __logf(u01_24(b3.y))));
-                            }
+                            const float4 ea = *reinterpret_cast<const float4*>(p.e1 + idx), eb = *reinterpret_cast<const float4*>(p.e2 + idx);
+                            la = make_float4(__logf(ea.x + TINYF_G), __logf(ea.y + TINYF_G), __logf(ea.z + TINYF_G), __logf(ea.w + TINYF_G));
+                            lb = make_float4(__logf(eb.x + TINYF_G), __logf(eb.y + TINYF_G), __logf(eb.z + TINYF_G), __logf(eb.w + TINYF_G));
                         }
-                        // hard sample: first maximum of l + g2 (the factor 1/tau > 0 does not move it, and the segment maxima are only
-                        // compared with one another)
                         const float h0 = v.x - lb.x, h1 = v.y - lb.y, h2 = v.z - lb.z, h3 = v.w - lb.w;
                         float b = h0; int bi = col;
                         if (h1 > b) { b = h1; bi = col + 1; }
@@ -414,7 +401,34 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                             if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }
                         }
                         if (b > hb[ps]) { hb[ps] = b; hi[ps] = bi; }          // later patches hold higher columns: only a strictly larger value wins
-                        // soft sample scores
+                        v.x = (v.x - la.x) * p.e_scale; v.y = (v.y - la.y) * p.e_scale; v.z = (v.z - la.z) * p.e_scale; v.w = (v.w - la.w) * p.e_scale;
+                    } else if (EPI == 2) {
+                        // device RNG.  The hard sample argmax(l + g2) is a draw from Categorical(soft-max(l)); it is taken by inverse CDF in
+                        // softmax_stat_combine_kernel (two uniforms per ROW) from the per-segment (max l, sum exp(l - max)) pairs gathered here,
+                        // instead of a second Gumbel draw per vocabulary entry (a hash, two logarithms and a compare per element less)
+                        {
+                            float hm = cok ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : -INFINITY;
+#pragma unroll
+                            for (int o = 1; o < 8; o <<= 1) hm = fmaxf(hm, __shfl_xor(hm, o, 64));
+                            float he = cok ? (__expf(v.x - hm) + __expf(v.y - hm)) + (__expf(v.z - hm) + __expf(v.w - hm)) : 0.f;
+#pragma unroll
+                            for (int o = 1; o < 8; o <<= 1) he += __shfl_xor(he, o, 64);
+                            if (hm > -INFINITY) {
+                                const float mn = fmaxf(hb[ps], hm);
+                                hs[ps] = hs[ps] * __expf(hb[ps] - mn) + he * __expf(hm - mn);
+                                hb[ps] = mn;
+                            }
+                        }
+                        // soft sample scores (l + g1) / tau, g1 = -log(E + tiny), E = -log(u): the draws of gumbel_softmax_kernel (element
+                        // index as the counter), the key taken once per four elements.  The + tiny guard is live: the largest 24-bit
+                        // uniform rounds to 1.0f, E = -log(1) = 0 (about 64 of the 10^9 draws of a step at B = 128)
+                        float4 la = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) {
+                            const uint64_t idx = (uint64_t)row * (uint64_t)p.N + col;
+                            const uint32_t key = rng_key(p.e_seed, SITE_GUMBEL_Z, (uint32_t)(idx >> 32)), lo = (uint32_t)idx;
+                            la = make_float4(__logf(TINYF_G - __logf(u01_24(rng_bits1_keyed(key, lo)))), __logf(TINYF_G - __logf(u01_24(rng_bits1_keyed(key, lo + 1)))),
+                                             __logf(TINYF_G - __logf(u01_24(rng_bits1_keyed(key, lo + 2)))), __logf(TINYF_G - __logf(u01_24(rng_bits1_keyed(key, lo + 3)))));
+                        }
                         v.x = (v.x - la.x) * p.e_scale; v.y = (v.y - la.y) * p.e_scale; v.z = (v.z - la.z) * p.e_scale; v.w = (v.w - la.w) * p.e_scale;
                     }
                     float lm = cok ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : -INFINITY;
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(256, (BM * BN == 128 * 128) ? 3 : ((BM * BN == 128 
                     const size_t si = (size_t)row * nseg + seg;
                     p.stat[si * 2] = sm[ps];
                     p.stat[si * 2 + 1] = ss[ps];
-                    if (EPI == 2) { p.hstat[si] = hb[ps]; p.hidx[si] = hi[ps]; }
+                    if (EPI == 2) { p.hstat[si] = hb[ps]; p.hidx[si] = p.e1 ? hi[ps] : __builtin_bit_cast(int, hs[ps]); }
                 }
             }
         }

@@ -103,7 +103,8 @@ int gumbel_softmax_launch(const float* raw, const float* e1, const float* e2, fl
                           unsigned long long seed, hipStream_t st, float* zst = nullptr);
 int softmax_bwd_rows_launch(const float* z, float* d, long long R, int V, float scale, hipStream_t st);
 int softmax_stat_combine_launch(const float* stat, int nseg, long long R, float* lse, const float* hstat, const int* hidx, int* tokens,
-                                const float* pred, int ldp, const int* tok, float* out, float scale, float* ws, size_t ws_floats, hipStream_t st);
+                                const float* pred, int ldp, const int* tok, float* out, float scale, float* ws, size_t ws_floats, hipStream_t st,
+                                const float* cdf_scores = nullptr, int cdf_V = 0, float cdf_tau = 1.f, unsigned long long cdf_seed = 0);
 int exp_rows_launch(const float* y, const float* lse, float* z, long long R, int V, hipStream_t st);
 int rowdot_bias64_launch(const float* g, const float* act, const float* bias, long long R, float* out, hipStream_t st);
 int ce_launch(float* pred, const int* tokens, float* out, long long R, int V, int B, int write_grad, float* ws, size_t ws_floats, hipStream_t st);

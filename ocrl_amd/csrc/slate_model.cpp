@@ -498,7 +498,10 @@ int SlateModel::fwd_dvae(const StepInputs& in, hipStream_t st) {
         a.epi_mode = 2; a.stat = zstat_; a.hstat = zhstat_; a.hidx = zhidx_; a.e1 = in.noise_z; a.e2 = in.noise_zh; a.e_seed = in.seed;
         a.e_scale = 1.0f / in.tau;
         RC(gemm_launch(a, st));
-        RC(softmax_stat_combine_launch(zstat_, gemm_stat_segments(V), BT, zlse_, zhstat_, zhidx_, tokens_, nullptr, 0, nullptr, nullptr, 0.f, nullptr, 0, st));
+        // hard sample: with injected noise the arg-max of l + g2 (segment maxima from the epilogue); with the device RNG a draw from
+        // Categorical(soft-max(l)) by inverse CDF over the segment masses (one pair of uniforms per row instead of a Gumbel draw per entry)
+        RC(softmax_stat_combine_launch(zstat_, gemm_stat_segments(V), BT, zlse_, zhstat_, zhidx_, tokens_, nullptr, 0, nullptr, nullptr, 0.f, nullptr, 0, st,
+                                       in.noise_z ? nullptr : zraw_, V, in.tau, in.seed));
         have_scores_ = true;
     } else {
     RC(lin_fwd(de_[6], 64, P("_dvae._encoder.7.weight"), P("_dvae._encoder.7.bias"), zraw_, V, BT, V, 64, 0, nullptr, 0, 0.f, 0, st));

@@ -269,6 +269,47 @@ def test_device_rng_statistics():
     assert torch.isfinite(out[0][0][:3]).all()
 
 
+def test_device_hard_sample_follows_the_softmax():
+    """Device-RNG mode draws the hard Gumbel sample (slate_module.py:127: argmax of logits + Gumbel noise, i.e. a draw from
+    Categorical(soft-max(logits))) by inverse CDF over per-segment masses (csrc/elementwise.hip softmax_stat_combine_kernel).  Over many
+    seeds the token counts must follow soft-max(logits) of each position: per vocabulary entry the standardised count deviation stays
+    inside +-5 sigma, and entries no position gives mass to are never drawn."""
+    cfg = O.default_cfg(obs_size=16, vocab_size=256, num_slots=3, num_iterations=1, num_dec_blocks=1)
+    B, T, V = 8, 16, cfg.vocab_size
+    P = O.formula_params(cfg)
+    eng = make_engine(cfg, B)
+    load_params(eng, P)
+    # flatter logits than the closed-form weights give: scale the head so that many entries carry mass
+    eng.param("_dvae._encoder.7.weight").mul_(0.05)
+    eng.param("_dvae._encoder.7.bias").mul_(0.05)
+    obs = torch.rand(B, 3, 16, 16, generator=torch.Generator().manual_seed(3)).cuda()
+    eng.forward(obs, 1.0, train=False, seed=1)
+    h = eng.tensor("dvae_enc6", (B * T, 64)).double().cpu()
+    W = eng.param("_dvae._encoder.7.weight").reshape(V, 64).double().cpu()
+    bias = eng.param("_dvae._encoder.7.bias").double().cpu()
+    prob = torch.softmax(h @ W.T + bias, -1)                       # [B*T, V]
+    nrun = 400
+    counts = torch.zeros(B * T, V, dtype=torch.float64)
+    for seed in range(nrun):
+        eng.forward(obs, 1.0, train=False, seed=1000 + seed)
+        tok = eng.tensor("tokens", (B * T,), torch.int32).cpu().long()
+        counts[torch.arange(B * T), tok] += 1
+    exp = nrun * prob
+    var = (nrun * prob * (1 - prob)).sum(0)
+    z = (counts.sum(0) - exp.sum(0)) / var.clamp_min(1e-9).sqrt()
+    live = var > 1.0
+    assert live.sum() >= 8, "the test needs several vocabulary entries with mass"
+    assert z[live].abs().max() < 5.0, (z[live].abs().max(), int(live.sum()))
+    assert counts.sum(0)[exp.sum(0) < 1e-6].sum() == 0                 # entries without mass are never drawn
+    # per position: the most likely token is drawn about as often as its probability says
+    top = prob.argmax(-1)
+    ptop = prob[torch.arange(B * T), top]
+    ctop = counts[torch.arange(B * T), top]
+    zt = (ctop - nrun * ptop) / (nrun * ptop * (1 - ptop)).clamp_min(1e-9).sqrt()
+    assert zt.abs().max() < 5.0, zt.abs().max()
+    log(f"[hard sample] {nrun} seeds x {B * T} positions: max |z| over {int(live.sum())} vocabulary entries {z[live].abs().max():.2f}, over the positions' top tokens {zt.abs().max():.2f}")
+
+
 BC = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=1, use_bcdec=True)
 BC32 = dict(obs_size=32, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, use_bcdec=True)
 BC12 = dict(obs_size=16, vocab_size=256, num_slots=12, num_iterations=2, num_dec_blocks=1, use_bcdec=True)      # more than 8 slots
