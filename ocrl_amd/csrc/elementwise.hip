@@ -1176,10 +1176,13 @@ __device__ inline float slot_eps(const float* noise, long long i, unsigned long 
     const uint2 b = rng_bits4(seed, SITE_SLOT_NOISE, (uint64_t)i);
     return sqrtf(-2.0f * __logf(u01_24(b.x))) * __cosf(6.2831853f * u01_24(b.y));
 }
+__global__ void store_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
+// seed_dev (optional): the seed is read from device memory, so that a captured launch (hipGraph) can be replayed with a new one
 __global__ void slot_init_kernel(const float* __restrict__ mu, const float* __restrict__ logsig, const float* __restrict__ noise,
-                                 float* __restrict__ slots0, long long n, int D, unsigned long long seed) {
+                                 float* __restrict__ slots0, long long n, int D, unsigned long long seed, const unsigned long long* __restrict__ seed_dev) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (seed_dev) seed = *seed_dev;
     const int c = i % D;
     slots0[i] = mu[c] + __expf(logsig[c]) * slot_eps(noise, i, seed);
 }
@@ -1607,9 +1610,15 @@ int pad_cols_launch(const float* in, int ldi, float* out, int ldo, long long R, 
     OCRL_CHECK_LAUNCH("pad_cols");
     return 0;
 }
-int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st) {
+int store_u64_launch(unsigned long long* dst, unsigned long long v, hipStream_t st) {
+    hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, st, dst, v);
+    OCRL_CHECK_LAUNCH("store_u64");
+    return 0;
+}
+int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st,
+                     const unsigned long long* seed_dev) {
     const long long n = (long long)BK * D;
-    hipLaunchKernelGGL(slot_init_kernel, GRID1D(n), 0, st, mu, logsig, noise, slots0, n, D, seed);
+    hipLaunchKernelGGL(slot_init_kernel, GRID1D(n), 0, st, mu, logsig, noise, slots0, n, D, seed, seed_dev);
     OCRL_CHECK_LAUNCH("slot_init");
     return 0;
 }

@@ -225,7 +225,9 @@ int absmax_launch(const float* g, long long n, float* out, float* ws, size_t ws_
 // g is first scaled by gscale (1/world for data parallel mean), then clipped by the inf-norm in norm[0]*gscale
 int clip_adam_launch(float* p, const float* g, float* m, float* v, long long n, const float* norm, float clip, float lr, float b1,
                      float b2, float eps, int step, float gscale, hipStream_t st);
-int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st);
+int store_u64_launch(unsigned long long* dst, unsigned long long v, hipStream_t st);
+int slot_init_launch(const float* mu, const float* logsig, const float* noise, float* slots0, int BK, int D, unsigned long long seed, hipStream_t st,
+                     const unsigned long long* seed_dev = nullptr);
 int slot_init_bwd_launch(const float* dslots0, const float* logsig, const float* noise, float* dmu, float* dlogsig, int BK, int D, unsigned long long seed, hipStream_t st);
 int copy_launch(const float* src, float* dst, long long n, hipStream_t st);
 int argmax_pos_launch(const float* pred, int* tokens, int B, int T, int V, int t, hipStream_t st, int dense_rows = 0);

@@ -112,9 +112,11 @@ SlateModel::~SlateModel() {
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_tokens_) (void)hipEventDestroy(ev_tokens_);
     if (side_) (void)hipStreamDestroy(side_);
+    for (auto& kv : enc_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     for (hipEvent_t e : ev_dw_) if (e) (void)hipEventDestroy(e);
     if (ev_join2_) (void)hipEventDestroy(ev_join2_);
     if (side2_) (void)hipStreamDestroy(side2_);
+    if (cap_) (void)hipStreamDestroy(cap_);
 }
 
 float* SlateModel::P(const std::string& n) const { return p_ + params_[index_.at(n)].offset; }
@@ -150,6 +152,8 @@ void SlateModel::layout_workspace(bool commit) {
     scratch_ = carve(nullptr, scratch_floats_);
     scratch2_ = cfg.use_bcdec ? scratch_ : carve(nullptr, scratch_floats_);
     obs8_ = carve("obs8", BN * 8);
+    obs_stage_ = carve(nullptr, (B < 32 ? B : 32) * (size_t)cfg.obs_channels * N);
+    seed_dev_ = reinterpret_cast<unsigned long long*>(carve(nullptr, 64));
     e1_ = carve("enc1", BN * 64); e2_ = carve("enc2", BN * 64); e3_ = carve("enc3", BN * 64); e4_ = carve("feats", BN * 64);
     posmap_ = carve(nullptr, (size_t)N * C); gridT_ = carve(nullptr, (size_t)N * 4);
     ln0_ = carve(nullptr, BN * 64); ln0_mean_ = carve(nullptr, BN); ln0_rstd_ = carve(nullptr, BN);
@@ -266,6 +270,8 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     p_ = p; g_ = g; m_ = m; v_ = v;
     ws_ = static_cast<char*>(ws);
     named_.clear();
+    for (auto& kv : enc_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);      // captured against the old buffers
+    enc_graphs_.clear();
     layout_workspace(true);
     if (!side_) {
         // OCRL_OVERLAP (default 5): the dVAE branch (many short 64-wide products that do not fill the machine) runs on a side stream.
@@ -423,12 +429,12 @@ int SlateModel::conv_layer_wgrad(const float* x, const float* dy, float* dW, flo
     return 0;
 }
 
-int SlateModel::pack_weights(hipStream_t st) {
+int SlateModel::pack_weights(hipStream_t st, bool encoder_only) {
     RC(conv_pack_launch(P("_enc._encoder.0.m.weight"), cw_fwd_[0], nullptr, 5, 8, 64, cfg.obs_channels, st));
     RC(conv_pack_launch(P("_enc._encoder.1.m.weight"), cw_fwd_[1], cw_bwd_[1], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_enc._encoder.2.m.weight"), cw_fwd_[2], cw_bwd_[2], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_enc._encoder.3.weight"), cw_fwd_[3], cw_bwd_[3], 5, 64, 64, 64, st));
-    if (!cfg.use_bcdec) {
+    if (!cfg.use_bcdec && !encoder_only) {
         RC(conv_pack_launch(P("_dvae._decoder.1.m.weight"), dw_fwd_[0], dw_bwd_[0], 3, 64, 64, 64, st));
         RC(conv_pack_launch(P("_dvae._decoder.6.m.weight"), dw_fwd_[1], dw_bwd_[1], 3, 64, 64, 64, st));
         RC(copy_launch(P("_dvae._decoder.11.weight"), w11p_, cfg.obs_channels * 64, st));    // [3,64] -> [4,64], row 3 zero
@@ -455,7 +461,7 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae)
     // weights and the noise only: issued first, they run on an otherwise idle machine.  After the fork their whole-CU-LDS workgroups
     // queue behind the Gumbel head's 32 768 small workgroups on the side stream (measured: 1.46 ms instead of 60 us, on the critical
     // path of the decoder)
-    RC(slot_init_launch(P("_slotattn.slot_mu"), P("_slotattn.slot_log_sigma"), in.noise_slots, slots0_, B * K, D, in.seed, st));
+    RC(slot_init_launch(P("_slotattn.slot_mu"), P("_slotattn.slot_log_sigma"), in.noise_slots, slots0_, B * K, D, in.seed, st, in.seed_dev));
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
     a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
@@ -679,9 +685,40 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
     OCRL_REQUIRE(in.B >= 1 && in.B <= Bmax && in.obs, "encode: bad inputs");
     last_ = in;
     pdrop_ = 0.f;
-    RC(pack_weights(st));
-    RC(fwd_encoder(in, st));
     have_fwd_ = false;
+    // measured (tools/bench_encode.py, B = 1 / 8 / 32 at 64x64): 0.457 / 0.483 / 1.006 ms replayed against 0.450 / 0.473 / 0.988 ms eager -- the
+    // call is bound by its chain of ~30 dependent small kernels on the GPU, not by the host's launches, so the replay is opt-in
+    if (enc_graph_mode_ < 0) { const char* e = getenv("OCRL_ENCODE_GRAPH"); enc_graph_mode_ = e ? atoi(e) : 0; }
+    const bool graph = enc_graph_mode_ && in.B <= 32 && !in.noise_slots && obs_stage_;
+    if (!graph) {
+        RC(pack_weights(st, true));
+        return fwd_encoder(in, st);
+    }
+    EncGraph& eg = enc_graphs_[in.B];
+    if (!eg.warm) {            // first call at this batch size runs eagerly: one-time kernel attributes are set outside the capture
+        eg.warm = 1;
+        RC(pack_weights(st, true));
+        return fwd_encoder(in, st);
+    }
+    const size_t bytes = (size_t)in.B * cfg.obs_channels * N * sizeof(float);
+    OCRL_HIP(hipMemcpyAsync(obs_stage_, in.obs, bytes, hipMemcpyDeviceToDevice, st));
+    RC(store_u64_launch(seed_dev_, in.seed, st));
+    if (!eg.exec) {
+        StepInputs gi = in;
+        gi.obs = obs_stage_; gi.seed_dev = seed_dev_;
+        hipGraph_t g = nullptr;
+        // captured on a stream of its own (the caller's may be the legacy default stream, which cannot capture); replayed on the caller's
+        if (!cap_) OCRL_HIP(hipStreamCreateWithFlags(&cap_, hipStreamNonBlocking));
+        OCRL_HIP(hipStreamBeginCapture(cap_, hipStreamCaptureModeThreadLocal));
+        int rc = pack_weights(cap_, true);
+        if (!rc) rc = fwd_encoder(gi, cap_);
+        const hipError_t ce = hipStreamEndCapture(cap_, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        OCRL_HIP(ce);
+        OCRL_HIP(hipGraphInstantiate(&eg.exec, g, nullptr, nullptr, 0));
+        OCRL_HIP(hipGraphDestroy(g));
+    }
+    OCRL_HIP(hipGraphLaunch(eg.exec, st));
     return 0;
 }
 

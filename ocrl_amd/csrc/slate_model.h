@@ -35,6 +35,7 @@ struct StepInputs {
     const float* noise_z = nullptr;    // optional injected Exp(1) draws [B,T,V] (both or none)
     const float* noise_zh = nullptr;
     const float* noise_slots = nullptr;  // optional injected N(0,1) [B,K,D]
+    const unsigned long long* seed_dev = nullptr;   // internal: the slot-noise seed read from device memory (captured encode graphs)
 };
 
 // dropout-backward mask applied to dy while the GEMM stages it
@@ -84,7 +85,7 @@ private:
                        const float* posmap, const float* mask, hipStream_t st);
     int conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN, int cin_real,
                          hipStream_t st);
-    int pack_weights(hipStream_t st);
+    int pack_weights(hipStream_t st, bool encoder_only = false);
     int fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae = 0);
     int fwd_dvae(const StepInputs& in, hipStream_t st);
     int fwd_decoder(hipStream_t st, bool with_ce = true);
@@ -154,6 +155,15 @@ private:
     // d q|k|v (OCRL_DW_SIDE; without it every block uses the first set)
     struct BlkG { float *gbr[3], *gf1, *gt2, *gqkv, *xaPd, *xaDs; };
     std::vector<BlkG> bg_;
+    // inference path of the RL feature extractor (sb3s/ocr_extractor.py:45) at tiny batches: the ~30 launches of encode() are captured once
+    // per batch size into a hipGraph and replayed (OCRL_ENCODE_GRAPH=1, opt-in: measured no faster; B <= 32, device RNG).  The observation is staged into a
+    // fixed buffer and the seed passed through device memory, so a replay sees new inputs.
+    struct EncGraph { hipGraphExec_t exec = nullptr; int warm = 0; };
+    std::map<int, EncGraph> enc_graphs_;
+    int enc_graph_mode_ = -1;
+    hipStream_t cap_ = nullptr;
+    float* obs_stage_ = nullptr;
+    unsigned long long* seed_dev_ = nullptr;
     int dw_mode_ = 0;                     // OCRL_DW_SIDE: 0 weight gradients of the decoder on the main stream, 1 on the dVAE side stream, 2 on a stream of their own
     hipStream_t side2_ = nullptr;
     float* scratch3_ = nullptr;

@@ -39,6 +39,29 @@ class _PositionalEncoding(nn.Module):
         self.register_buffer("pe", pe)
 
 
+class _SinusoidalEncoding(nn.Module):
+    """poolings/transformer/transformer_module.py:11-24: rows of the table se[i, 2j] = sin(i w_j), se[i, 2j+1] = cos(i w_j).  The reference
+    materialises max_len + 1 rows as a buffer (`se`: 5 GB for push_embedding's max_len = 10^7); here the requested rows are evaluated
+    on the fly (the same fp32 products), so the module has no `se` entry in its state_dict and ignores one when a reference checkpoint
+    is loaded."""
+
+    def __init__(self, d_model, max_len):
+        super().__init__()
+        self.d_model, self.max_len = d_model, max_len
+        self.register_buffer("div_term", torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model)), persistent=False)
+
+    def forward(self, idx):
+        inp = idx.to(torch.float32).unsqueeze(-1)
+        out = torch.empty(*idx.shape, self.d_model, device=idx.device, dtype=torch.float32)
+        out[..., 0::2] = torch.sin(inp * self.div_term)
+        out[..., 1::2] = torch.cos(inp * self.div_term)
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        state_dict.pop(prefix + "se", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
 class _LinearFn(torch.autograd.Function):
     """y = [relu](x W^T + b) on rows, forward and backward through the library's MFMA GEMM (include/ocrl_hip.h ocrl_gemm: NT with fused
     bias / ReLU, NN with the ReLU mask for dx, TN for dW) — the slot MLPs in front of the pooling transformer (transformer_module.py:47-63)"""
@@ -50,9 +73,13 @@ class _LinearFn(torch.autograd.Function):
         L = _lib.lib()
         shp = x.shape
         x2 = x.reshape(-1, shp[-1]).contiguous().float()
+        w, b = weight.detach().contiguous(), bias.detach().contiguous()
+        ctx.kpad = (-x2.shape[1]) % 4            # the GEMM wants a k extent that is a multiple of 4 (obj_emb of cw_embedding: 3*128 + 3 inputs)
+        if ctx.kpad:
+            x2 = torch.nn.functional.pad(x2, (0, ctx.kpad))
+            w = torch.nn.functional.pad(w, (0, ctx.kpad))
         M, K = x2.shape
         N = weight.shape[0]
-        w, b = weight.detach().contiguous(), bias.detach().contiguous()
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         _lib.check(L.ocrl_gemm(_lib.ptr(x2), _lib.ptr(w), _lib.ptr(y), M, N, K, K, K, N, 1, 1, 1.0, _lib.ptr(b), int(relu), None, 0, None, 0, 1, None, st))
@@ -74,9 +101,13 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)           # dx = dy W        (NN)
             _lib.check(L.ocrl_gemm(_lib.ptr(dy2), _lib.ptr(w), _lib.ptr(dx), M, K, N, N, K, K, 1, 0, 1.0, None, 0, None, 0, None, 0, 1, None, st))
+            if ctx.kpad:
+                dx = dx[:, :K - ctx.kpad]
             dx = dx.reshape(ctx.shape)
         dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)               # dW = dy^T x     (TN over the rows)
         _lib.check(L.ocrl_gemm(_lib.ptr(dy2), _lib.ptr(x2), _lib.ptr(dw), N, K, M, N, K, K, 0, 0, 1.0, None, 0, None, 0, None, 0, 1, None, st))
+        if ctx.kpad:
+            dw = dw[:, :K - ctx.kpad].contiguous()
         return dx, dw, dy2.sum(0), None
 
 
@@ -155,15 +186,32 @@ class Transformer_Module(nn.Module):
         super().__init__()
         self.rep_dim = d_model = config.d_model
         self.config = config
-        for flag in ("cw_embedding", "push_embedding"):        # embeddings of ground-truth state vectors (ocr=GT): not an image path
-            if getattr(config, flag, False):
-                raise NotImplementedError(f"pooling.{flag}=True is not built in this backend (transformer_module.py:65-78)")
         self.mlp = None
         if getattr(config, "use_mlp1", False):                  # transformer_module.py:47-53
             self.mlp = _slot_mlp([ocr_rep_dim, 64, 128])
             ocr_rep_dim = 128
         if getattr(config, "use_mlp2", False):                  # transformer_module.py:55-63 (replaces mlp1's module when both are set, as in the reference)
             self.mlp = _slot_mlp([ocr_rep_dim, 64, 64, 128])
+            ocr_rep_dim = 128
+        # embeddings of ground-truth state vectors (the ocr=GT encoders; transformer_module.py:65-78): quantised coordinates index a
+        # sinusoid table, ids index nn.Embedding tables, the Linears to 128 run on the library's GEMM (gathers / concatenations are glue)
+        self._cw = bool(getattr(config, "cw_embedding", False))
+        self._push = bool(getattr(config, "push_embedding", False))
+        if self._cw or self._push:
+            if d_model != 128:
+                raise ValueError("cw_embedding / push_embedding build 128-wide object embeddings: pooling.d_model must be 128 (transformer_module.py:65-78)")
+        if self._cw:
+            self.max_len = 10000
+            self.cw_emb = _SinusoidalEncoding(d_model, self.max_len)
+            self.arm_emb = _HipLinear(28 * d_model, 128)
+            self.obj_emb = _HipLinear(3 * d_model + 3, 128)
+            ocr_rep_dim = 128
+        if self._push:
+            self.max_len = 10000000
+            self.color_emb = nn.Embedding(10, 128)
+            self.shape_emb = nn.Embedding(10, 128)
+            self.pos_emb = _SinusoidalEncoding(d_model, self.max_len)
+            self.obj_emb = _HipLinear(4 * d_model, 128)
             ocr_rep_dim = 128
         if num_stacked_obss > 1:
             pos = _PositionalEncoding(ocr_num_slots * num_stacked_obss + 1, d_model, num_stacked_obss)
@@ -188,7 +236,24 @@ class Transformer_Module(nn.Module):
                    l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
         return ps
 
+    def get_pos_emb(self, emb, x):
+        """transformer_module.py:82-87: [-1, 1] -> table row"""
+        x = torch.clamp((x + 1) / 2, 0.0, 1.0)
+        return emb((x // (1 / self.max_len)).long())
+
     def forward(self, state):
+        if self._push:                                          # transformer_module.py:90-96
+            color = self.color_emb(state[:, :, 0].long())
+            shape = self.shape_emb(state[:, :, 1].long())
+            pos = self.get_pos_emb(self.pos_emb, state[:, :, -2:])
+            state = self.obj_emb(torch.cat([color, shape, pos[:, :, 0], pos[:, :, 1]], dim=-1))
+        if self._cw:                                            # transformer_module.py:98-111
+            B, K, _ = state.shape
+            arm = self.arm_emb(self.get_pos_emb(self.cw_emb, state[:, 0, :28]).view(B, -1))
+            obj = state[:, 1:, 28:]
+            obj_pos = self.get_pos_emb(self.cw_emb, obj[:, :, :3].reshape(-1, 3)).reshape(B, K - 1, -1)
+            objs = self.obj_emb(torch.cat([obj_pos, obj[:, :, 7:10]], dim=-1))
+            state = torch.cat([arm.unsqueeze(1), objs], dim=1)
         if self.mlp is not None:                                # transformer_module.py:103-104
             state = self.mlp(state)
         pos = None if self._trans._pos is None else self._trans._pos.pe[: state.shape[1] + 1, 0].contiguous()

@@ -114,6 +114,63 @@ def forward(P, slots, cfg, masks=None, p_drop=0.0):
     return x[:, 0]
 
 
+# ---- embeddings of ground-truth state vectors in front of the transformer (poolings/transformer/transformer_module.py:65-101, the
+# cw_embedding / push_embedding switches of ocr=GT): sinusoidal tables indexed by quantised coordinates, two nn.Embedding tables, one or
+# two Linears to 128.  Pinned by tests/golden/pooling_cw.npz / pooling_push.npz (made from the reference module).
+def sinusoid(idx, d_model):
+    """rows `idx` of the reference's SinusoidalEncoding table (transformer_module.py:11-24): se[i, 2j] = sin(i w_j), se[i, 2j+1] = cos(i w_j)"""
+    inp = idx.to(torch.float32).unsqueeze(-1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    out = torch.zeros(*idx.shape, d_model, dtype=torch.float32)
+    out[..., 0::2] = torch.sin(inp * div_term)
+    out[..., 1::2] = torch.cos(inp * div_term)
+    return out
+
+
+def quantise(x, max_len):
+    """get_pos_emb (transformer_module.py:82-87): [-1, 1] -> table index"""
+    x = torch.clamp((x + 1) / 2, 0.0, 1.0)
+    return (x // (1 / max_len)).long()
+
+
+def gt_param_shapes(mode, d_model=128):
+    if mode == "cw":
+        return [("arm_emb.weight", (128, 28 * d_model)), ("arm_emb.bias", (128,)), ("obj_emb.weight", (128, 3 * d_model + 3)), ("obj_emb.bias", (128,))]
+    return [("color_emb.weight", (10, 128)), ("shape_emb.weight", (10, 128)), ("obj_emb.weight", (128, 4 * d_model)), ("obj_emb.bias", (128,))]
+
+
+def gt_formula_params(mode, d_model=128):
+    P = {}
+    for i, (name, shape) in enumerate(gt_param_shapes(mode, d_model)):
+        n = 1
+        for s in shape:
+            n *= s
+        v = torch.sin(torch.arange(n, dtype=torch.float64) * (0.23 + 0.017 * i) + 0.9 * i)
+        if len(shape) == 2 and (name.startswith("arm_emb") or name.startswith("obj_emb")):
+            v = v / math.sqrt(shape[1])          # Linear weights
+        else:
+            v = 0.5 * v                          # embedding tables, biases
+        P[name] = v.reshape(shape).float()
+    return P
+
+
+def gt_embed(G, state, mode, d_model=128):
+    """state [B,K,*] of ground-truth vectors -> [B,K,128] (the tensor the transformer's input Linear consumes)"""
+    if mode == "push":                      # transformer_module.py:90-96
+        color = G["color_emb.weight"][state[:, :, 0].long()]
+        shape = G["shape_emb.weight"][state[:, :, 1].long()]
+        pos = sinusoid(quantise(state[:, :, -2:], 10000000), d_model).to(state.dtype)
+        x = torch.cat([color, shape, pos[:, :, 0], pos[:, :, 1]], dim=-1)
+        return x @ G["obj_emb.weight"].T + G["obj_emb.bias"]
+    B, K, _ = state.shape                   # transformer_module.py:98-111
+    arm = sinusoid(quantise(state[:, 0, :28], 10000), d_model).to(state.dtype).reshape(B, -1)
+    arm = arm @ G["arm_emb.weight"].T + G["arm_emb.bias"]
+    obj = state[:, 1:, 28:]
+    opos = sinusoid(quantise(obj[:, :, :3].reshape(-1, 3), 10000), d_model).to(state.dtype).reshape(B, K - 1, -1)
+    ob = torch.cat([opos, obj[:, :, 7:10]], dim=-1) @ G["obj_emb.weight"].T + G["obj_emb.bias"]
+    return torch.cat([arm.unsqueeze(1), ob], dim=1)
+
+
 def loss_and_grads(P, slots, cfg, cot, masks=None, p_drop=0.0, dtype=torch.float32):
     """out, d<out, cot>/dP, d<out, cot>/dslots"""
     Q = {k: v.detach().to(dtype).requires_grad_(True) for k, v in P.items()}

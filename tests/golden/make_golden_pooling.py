@@ -108,12 +108,64 @@ def run_case(Mod, tag, over, B, train):
     return fx
 
 
+def gt_states(mode, B, K, seed):
+    """seeded ground-truth state vectors in the ranges the embeddings index (transformer_module.py:82-111)"""
+    g = torch.Generator().manual_seed(seed)
+    if mode == "push":          # [colour id, shape id, ..., x, y]
+        return torch.cat([torch.randint(0, 10, (B, K, 2), generator=g).float(), torch.rand(B, K, 2, generator=g) * 2.4 - 1.2], dim=-1)
+    return torch.rand(B, K, 28 + 10, generator=g) * 2.4 - 1.2      # row 0: 28 arm coordinates; rows 1..: [28:31] position, [35:38] colour
+
+
+def run_gt_case(Mod, mode):
+    """cw_embedding / push_embedding (transformer_module.py:65-111): the reference module on seeded states, closed-form weights"""
+    cfg = PO.default_cfg(rep_dim=128, num_slots=5, d_model=128)
+    rc = ref_config(cfg)
+    setattr(rc, "cw_embedding" if mode == "cw" else "push_embedding", True)
+    m = Mod(cfg.rep_dim, cfg.num_slots, rc)          # push: builds the reference's 10^7-row sinusoid table (5 GB, tens of seconds)
+    P, G = PO.formula_params(cfg), PO.gt_formula_params(mode)
+    sd = m.state_dict()
+    extra = [k for k in sd if not k.startswith("_trans.") and not k.endswith(".se")]
+    assert sorted(extra) == sorted(G), (extra, sorted(G))
+    m.load_state_dict({**sd, **P, **G})
+    m.eval()
+    B, K = 3, cfg.num_slots
+    state = gt_states(mode, B, K, 21)
+    cot = torch.randn(B, cfg.d_model, generator=torch.Generator().manual_seed(22))
+    out = m(state)
+    (out * cot).sum().backward()
+    ref_g = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    # oracle: embedding restatement + the pinned transformer restatement
+    Gq = {k: v.clone().requires_grad_(True) for k, v in G.items()}
+    Pq = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    emb = PO.gt_embed(Gq, state, mode)
+    o = PO.forward(Pq, emb, cfg)
+    (o * cot).sum().backward()
+    err = (o.detach() - out.detach()).abs().max().item() / out.detach().abs().max().item()
+    assert err < 2e-5, (mode, err)
+    gmax = max(v.abs().max().item() for v in ref_g.values())
+    for n in G:
+        e = (Gq[n].grad - ref_g[n]).abs().max().item() / max(ref_g[n].abs().max().item(), 1e-6 * gmax)
+        assert e < 2e-4, (mode, n, e)
+    print(f"[{mode}_embedding] oracle == reference (out {err:.1e})")
+    fx = {"state": state.numpy(), "cot": cot.numpy(), "out": out.detach().numpy(), "emb": emb.detach().numpy()}
+    for n in G:
+        t = ref_g[n].double().flatten()
+        fx["g:" + n] = np.concatenate([np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()]), t[:: max(1, t.numel() // 509)][:509].numpy()])
+    np.savez_compressed(os.path.join(HERE, f"pooling_{mode}.npz"), **fx)
+
+
 def main():
     Mod = import_reference()
     torch.manual_seed(0)
+    if "--only-gt" in sys.argv:
+        run_gt_case(Mod, "cw")
+        run_gt_case(Mod, "push")
+        return
     for tag, c in CASES.items():
         np.savez_compressed(os.path.join(HERE, f"pooling_{tag}.npz"), **run_case(Mod, tag, c["over"], c["B"], False))
     np.savez_compressed(os.path.join(HERE, "pooling_default_train.npz"), **run_case(Mod, "default", CASES["default"]["over"], 2, True))
+    run_gt_case(Mod, "cw")
+    run_gt_case(Mod, "push")
 
 
 if __name__ == "__main__":

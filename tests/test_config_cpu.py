@@ -129,8 +129,15 @@ def test_pooling_module_mirrors_reference_state_dict():
             assert torch.allclose(sd["_trans._pos.pe"][:, 0], PO.pos_table(cfg))
         with pytest.raises(RuntimeError):
             m(torch.zeros(2, cfg.num_slots, cfg.rep_dim))
-    with pytest.raises(NotImplementedError):
-        Transformer_Module(64, 4, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", cw_embedding=True))
+    # cw_embedding / push_embedding (transformer_module.py:65-78): the reference's parameter names; its materialised sinusoid table `se` is
+    # evaluated on the fly and ignored when a reference checkpoint carries it
+    mc = Transformer_Module(64, 4, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", cw_embedding=True))
+    assert [(k, tuple(v.shape)) for k, v in mc.state_dict().items()][:4] == [("arm_emb.weight", (128, 3584)), ("arm_emb.bias", (128,)), ("obj_emb.weight", (128, 387)), ("obj_emb.bias", (128,))]
+    mc.load_state_dict({**mc.state_dict(), "cw_emb.se": torch.zeros(10001, 1, 128)})
+    mp = Transformer_Module(64, 4, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", push_embedding=True))
+    assert [k for k in mp.state_dict() if not k.startswith("_trans.")] == ["color_emb.weight", "shape_emb.weight", "obj_emb.weight", "obj_emb.bias"]
+    with pytest.raises(ValueError):
+        Transformer_Module(64, 4, types.SimpleNamespace(d_model=256, nhead=8, num_layers=1, pos_emb="None", cw_embedding=True))
     # use_mlp1 / use_mlp2 (transformer_module.py:47-63): the slot MLP's keys and shapes are the reference nn.Sequential's
     m1 = Transformer_Module(192, 6, types.SimpleNamespace(d_model=128, nhead=8, num_layers=1, pos_emb="None", use_mlp1=True))
     assert [(k, tuple(v.shape)) for k, v in m1.state_dict().items()][:4] == [("mlp.0.weight", (64, 192)), ("mlp.0.bias", (64,)), ("mlp.2.weight", (128, 64)), ("mlp.2.bias", (128,))]

@@ -229,3 +229,33 @@ def test_slot_mlp_switches(flag, widths):
         errs += [relerr(m.mlp[2 * i].weight.grad, w.grad), relerr(m.mlp[2 * i].bias.grad, b.grad)]
     log(f"[pooling {flag}] output {e_out:.2e}; MLP weight / bias gradients worst {max(errs[1:]):.2e}")
     assert max(errs) < 3e-4, errs
+
+
+@pytest.mark.parametrize("mode", ["cw", "push"])
+def test_gt_state_embeddings_match_reference_fixture(mode):
+    """pooling.cw_embedding / push_embedding (transformer_module.py:65-111): the module on the GPU (Linears on the library's GEMM, transformer
+    on ocrl_pool_transformer_*) against the reference module's output and embedding-parameter gradients"""
+    from ocrl_amd.poolings import Transformer_Module
+    fx = np.load(os.path.join(GOLD, f"pooling_{mode}.npz"))
+    cfg = PO.default_cfg(rep_dim=128, num_slots=5, d_model=128)
+    rc = types.SimpleNamespace(d_model=128, nhead=cfg.nhead, num_layers=cfg.num_layers, pos_emb="None", norm_first=False, use_mlp1=False, use_mlp2=False,
+                               cw_embedding=mode == "cw", push_embedding=mode == "push")
+    m = Transformer_Module(128, cfg.num_slots, rc)
+    G = PO.gt_formula_params(mode)
+    sd = m.state_dict()
+    assert sorted(k for k in sd if not k.startswith("_trans.")) == sorted(G)          # the reference's parameter names (its `se` buffer is not kept)
+    m.load_state_dict({**sd, **PO.formula_params(cfg), **G})
+    m = m.cuda().eval()
+    out = m(torch.from_numpy(fx["state"]).cuda())
+    (out * torch.from_numpy(fx["cot"]).cuda()).sum().backward()
+    e_out = relerr(out, torch.from_numpy(fx["out"]))
+    named = dict(m.named_parameters())
+    gmax = max(np.abs(fx["g:" + n][3:]).max() for n in G)
+    worst = 0.0
+    for n in G:
+        ref = fx["g:" + n]
+        t = named[n].grad.double().flatten().cpu()
+        got = t[:: max(1, t.numel() // 509)][:509].numpy()
+        worst = max(worst, np.abs(got - ref[3:]).max() / max(np.abs(ref[3:]).max(), 1e-3 * gmax))
+    log(f"[pooling {mode}_embedding] output {e_out:.2e}; embedding-parameter gradients worst {worst:.2e}")
+    assert e_out < 2e-5 and worst < 3e-4

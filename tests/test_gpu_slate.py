@@ -216,6 +216,30 @@ def test_encode_matches_forward_slots():
     assert torch.allclose(a, torch.ones_like(a), atol=1e-5)      # softmax over slots sums to one at every position
 
 
+def test_encode_graph_replay_matches_eager(monkeypatch):
+    """the inference path at tiny batches (model(obs), slate_module.py:181-196) replays a captured hipGraph from its second call at a
+    batch size on (csrc/slate_model.cpp SlateModel::encode): every replay must see the new observation and the new noise seed, i.e.
+    equal the eager launches bit for bit"""
+    cfg = O.default_cfg(**SMALL)
+    P = O.formula_params(cfg)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OCRL_ENCODE_GRAPH", mode)
+        eng = make_engine(cfg, 4)
+        load_params(eng, P)
+        res = []
+        for i in range(5):
+            B = 2 if i != 3 else 4          # a second batch size in between: its own warm-up and graph
+            obs = torch.rand(B, 3, 16, 16, generator=torch.Generator().manual_seed(40 + i)).cuda()
+            eng.encode(obs, seed=90 + i)
+            torch.cuda.synchronize()
+            res.append((eng.tensor("slots", (B, 6, 192)).cpu().clone(), eng.tensor("attn", (B, 256, 6)).cpu().clone()))
+        outs[mode] = res
+    for (s1, a1), (s0, a0) in zip(outs["1"], outs["0"]):
+        assert torch.equal(s1, s0) and torch.equal(a1, a0)
+    assert not torch.equal(outs["1"][1][0], outs["1"][2][0])          # different observations / seeds give different slots
+
+
 def test_soft_sample_on_request():
     """The fused heads keep the Gumbel scores, not z: ocrl_slate_soft_z rebuilds z = softmax(scores) between forward and backward
     (get_loss(with_rep=True), slate_module.py:239-241) and refuses once the backward has overwritten the scores with their gradient;

@@ -207,3 +207,23 @@ def test_pooling_oracle_matches_reference(golden_dir, tag):
         ref, got = fx["g:" + n], _grad_summary(g[n])
         assert np.abs(got[3:] - ref[3:]).max() < 2e-4 * max(np.abs(ref[3:]).max(), 1e-3 * gmax), n
         assert abs(got[2] - ref[2]) <= 1e-3 * ref[2] + 1e-12, n
+
+
+@pytest.mark.parametrize("mode", ["cw", "push"])
+def test_gt_state_embeddings_match_reference(golden_dir, mode):
+    """oracle restatement of the cw_embedding / push_embedding front ends (transformer_module.py:65-111) + the pinned transformer against the
+    reference module's output and embedding-parameter gradients (tests/golden/make_golden_pooling.py run_gt_case)"""
+    from oracle import pooling_oracle as PO
+    fx = np.load(os.path.join(golden_dir, f"pooling_{mode}.npz"))
+    cfg = PO.default_cfg(rep_dim=128, num_slots=5, d_model=128)
+    P, G = PO.formula_params(cfg), PO.gt_formula_params(mode)
+    Gq = {k: v.clone().requires_grad_(True) for k, v in G.items()}
+    state, cot = torch.from_numpy(fx["state"]), torch.from_numpy(fx["cot"])
+    emb = PO.gt_embed(Gq, state, mode)
+    out = PO.forward(P, emb, cfg)
+    (out * cot).sum().backward()
+    assert np.abs(out.detach().numpy() - fx["out"]).max() < 2e-5 * np.abs(fx["out"]).max()
+    gmax = max(np.abs(fx["g:" + n][3:]).max() for n in G)
+    for n in G:
+        ref, got = fx["g:" + n], _grad_summary(Gq[n].grad)
+        assert np.abs(got[3:] - ref[3:]).max() < 2e-4 * max(np.abs(ref[3:]).max(), 1e-3 * gmax), n
