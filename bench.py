@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_HBM_GBS = 8000.0            # same guide: HBM3E ~8 TB/s
+PMC_ROUND = "r03"                # profiles/<round>_pmc_*.json: the committed rocprofv3 counter passes of this round's build
 FWD_FLOP_PER_IMAGE = {(128, 6): 22384148480, (64, 6): 5004001280, (256, 16): 129805844480}     # (S, slots), 3 iters
 
 
@@ -98,7 +99,7 @@ def committed_traffic(kernel_substr, B, S):
     """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None.
     Only used when the file says it was measured at this batch / image size; it is a profile of the same build, not a live counter."""
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_step_traffic.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", PMC_ROUND + "_pmc_step_traffic.json")))
         if tj.get("batch") != B or tj.get("obs_size") != S:
             return None
         for k, v in tj["kernels"].items():
@@ -150,11 +151,11 @@ def timed_region(args, dev, dist, step_fn, prof_mask):
 
 def committed_slot_attention_pmc(B, S):
     """matrix-pipe busy fraction, resident waves and HBM bytes per launch of the slot-attention kernels from this round's committed
-    rocprofv3 PMC passes over this same command (profiles/r02_pmc_slot_attention.json); None when measured at another shape"""
+    rocprofv3 PMC passes over this same command (profiles/<round>_pmc_slot_attention.json); None when measured at another shape"""
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_slot_attention.json")))
+        pj = json.load(open(os.path.join(ROOT, "profiles", PMC_ROUND + "_pmc_slot_attention.json")))
         if pj.get("batch") == B and pj.get("obs_size") == S:
-            return {"source": "profiles/r02_pmc_slot_attention.json (build %s)" % pj.get("build"),
+            return {"source": "profiles/%s_pmc_slot_attention.json (build %s)" % (PMC_ROUND, pj.get("build")),
                     **{k.replace("void ", ""): {q: (round(v, 3) if isinstance(v, float) and v < 100 else int(v)) for q, v in d.items()} for k, d in pj["kernels"].items()}}
     except Exception:
         pass
