@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define OCRL_ABI_VERSION 4
+#define OCRL_ABI_VERSION 5
 
 const char* ocrl_last_error(void);
 int ocrl_abi_version(void);
@@ -34,6 +34,8 @@ typedef struct ocrl_slate_config {
     int max_batch;                              /* workspace is sized for this many images */
     int use_bcdec;                              /* ocr_config.use_bcdec: Slot-Attention configuration (broadcast decoder) */
     int hard;                                   /* ocr_config.hard: straight-through Gumbel sample into the dVAE decoder */
+    int num_slot_heads;                         /* ocr_config.slotattr.num_slot_heads (ocrs/common/slot_attn.py:28,54-92); 0 is read as 1.
+                                                 * heads > 1: heads * num_slots <= 16, num_slots <= 8, (slot_size / heads) % 16 == 0 */
 } ocrl_slate_config;
 
 /* sizeof(ocrl_slate_config) as this library was built: a binding checks its own struct against it before ocrl_slate_create */
@@ -150,6 +152,13 @@ int ocrl_slot_attention_fwd(const float* x, const float* slots0, const float* co
                             int H, int I, float* ws, size_t ws_floats, void* stream);
 int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H,
                             int I, float* ws, size_t ws_floats, void* stream);
+/* the same with `heads` attention heads (ocrs/common/slot_attn.py:28,54-92: q / k / v split into heads, soft-max over heads * K columns,
+ * attn = sum over the heads): heads * K <= 16, K <= 8 and (D / heads) % 16 == 0 when heads > 1; heads = 1 is the pair above. */
+size_t ocrl_slot_attention_mh_ws_floats(int B, int N, int K, int D, int H, int I, int heads);
+int ocrl_slot_attention_mh_fwd(const float* x, const float* slots0, const float* const* w, float* slots, float* attn, int B, int N, int K, int D,
+                               int H, int I, int heads, float* ws, size_t ws_floats, void* stream);
+int ocrl_slot_attention_mh_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H,
+                               int I, int heads, float* ws, size_t ws_floats, void* stream);
 
 /* ---- slot-set pooling head: poolings/common/transformer.py:9-33 (Transformer: Linear -> [CLS; tokens] (+pos) ->
  * nn.TransformerEncoder of post-norm ReLU layers -> CLS row), as built by poolings/transformer/transformer_module.py:27-117 with its

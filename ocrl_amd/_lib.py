@@ -11,7 +11,7 @@ _lib = None
 class SlateConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("obs_size", "obs_channels", "vocab_size", "d_model", "cnn_hidden", "num_slots",
                                       "num_iterations", "slot_size", "mlp_hidden", "num_dec_blocks", "num_dec_heads")] + \
-               [("dropout", c_float), ("max_batch", c_int), ("use_bcdec", c_int), ("hard", c_int)]
+               [("dropout", c_float), ("max_batch", c_int), ("use_bcdec", c_int), ("hard", c_int), ("num_slot_heads", c_int)]
 
 
 class IodineConfig(ctypes.Structure):
@@ -97,6 +97,10 @@ def lib():
     L.ocrl_slot_attention_ws_floats.restype = c_size_t
     L.ocrl_slot_attention_fwd.argtypes = [p, p, POINTER(p), p, p, c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
     L.ocrl_slot_attention_bwd.argtypes = [p, p, p, p, POINTER(p), c_int, c_int, c_int, c_int, c_int, c_int, p, c_size_t, p]
+    L.ocrl_slot_attention_mh_ws_floats.argtypes = [c_int] * 7
+    L.ocrl_slot_attention_mh_ws_floats.restype = c_size_t
+    L.ocrl_slot_attention_mh_fwd.argtypes = [p, p, POINTER(p), p, p] + [c_int] * 7 + [p, c_size_t, p]
+    L.ocrl_slot_attention_mh_bwd.argtypes = [p, p, p, p, POINTER(p)] + [c_int] * 7 + [p, c_size_t, p]
     L.ocrl_pool_transformer_ws_floats.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int]
     L.ocrl_pool_transformer_ws_floats.restype = c_size_t
     L.ocrl_pool_transformer_fwd.argtypes = [p, POINTER(p), p, p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong, p, c_size_t, p]
@@ -109,7 +113,7 @@ def lib():
     L.ocrl_comm_world.argtypes = [p]
     L.ocrl_comm_destroy.argtypes = [p]
     L.ocrl_comm_destroy.restype = None
-    if L.ocrl_abi_version() != 4:
+    if L.ocrl_abi_version() != 5:
         raise RuntimeError("libocrl_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -53,6 +53,11 @@ int ocrl_slate_create(const ocrl_slate_config* c, ocrl_slate** out) {
     k.mlp_hidden = c->mlp_hidden; k.num_blocks = c->num_dec_blocks; k.num_heads = c->num_dec_heads; k.dropout = c->dropout;
     k.max_batch = c->max_batch;
     k.hard = c->hard ? 1 : 0; k.use_bcdec = c->use_bcdec ? 1 : 0;
+    k.slot_heads = c->num_slot_heads > 0 ? c->num_slot_heads : 1;
+    if (k.slot_heads > 1 && (c->num_slots > 8 || k.slot_heads * c->num_slots > 16 || c->slot_size % k.slot_heads || (c->slot_size / k.slot_heads) % 16)) {
+        ocrl_set_error("ocrl_slate_create: num_slot_heads %d needs heads * num_slots <= 16, num_slots <= 8 and a head width that is a multiple of 16", k.slot_heads);
+        return 1;
+    }
     if (k.use_bcdec && (c->num_slots > 16 || c->obs_size < 5)) { ocrl_set_error("ocrl_slate_create: broadcast decoder needs num_slots <= 16 and obs_size >= 5"); return 1; }
     ocrl_slate* h = new (std::nothrow) ocrl_slate;
     if (!h) { ocrl_set_error("out of memory"); return 1; }

@@ -175,28 +175,32 @@ static inline SaWts sa_wts_layout(int C, int D, int H) {
 }
 // Saved-activation matrix: one row per (image, iteration, slot), row = (b*I + t)*K + j, fields at fixed
 // column offsets, so every field is a strided [B*I*K, dim] GEMM operand with ld = sa_save_ld().
+// With NH attention heads (ocrs/common/slot_attn.py:54-61) the folded query, the weighted means and the weight sums exist per
+// (slot, head): qp / up / upn are NH blocks of C columns (head h at + h*C), csum NH values.
 struct SaSave { int sprev, sn, q, u, r, z, n, hn, sg, m, hid, qp, up, upn, csum, ld; };
-static inline SaSave sa_save_layout(int C, int D, int H) {
+static inline SaSave sa_save_layout(int C, int D, int H, int NH = 1) {
     SaSave o;
     o.sprev = 0; o.sn = D; o.q = 2 * D; o.u = 3 * D; o.r = 4 * D; o.z = 5 * D; o.n = 6 * D; o.hn = 7 * D; o.sg = 8 * D; o.m = 9 * D;
-    o.hid = 10 * D; o.qp = 10 * D + H; o.up = 10 * D + H + C; o.upn = 10 * D + H + 2 * C; o.csum = 10 * D + H + 3 * C; o.ld = 10 * D + H + 3 * C + 4;
+    o.hid = 10 * D; o.qp = 10 * D + H; o.up = o.qp + NH * C; o.upn = o.up + NH * C; o.csum = o.upn + NH * C; o.ld = o.csum + ((NH + 3) & ~3);
     return o;
 }
 // Gradient rows emitted by the backward kernel (same row index), consumed by the weight-gradient GEMMs.
 struct SaGrad { int out, hid, gi, gh, u, q, qp, ld; };
-static inline SaGrad sa_grad_layout(int C, int D, int H) {
+static inline SaGrad sa_grad_layout(int C, int D, int H, int NH = 1) {
     SaGrad o;
-    o.out = 0; o.hid = D; o.gi = D + H; o.gh = 4 * D + H; o.u = 7 * D + H; o.q = 8 * D + H; o.qp = 9 * D + H; o.ld = 9 * D + H + C;
+    o.out = 0; o.hid = D; o.gi = D + H; o.gh = 4 * D + H; o.u = 7 * D + H; o.q = 8 * D + H; o.qp = 9 * D + H; o.ld = 9 * D + H + NH * C;      // qp: NH blocks of C
     return o;
 }
 struct SlotAttnArgs {
     int B = 0, N = 0, C = 64, K = 0, D = 0, H = 0, I = 0;
-    float eps = 1e-8f, scale = 1.f;
+    int NH = 1;                      // attention heads (ocrs/common/slot_attn.py:28): the soft-max runs over NH*K columns; NH*K <= 16, K <= 8 when NH > 1
+    float eps = 1e-8f, scale = 1.f;  // scale = (D / NH)^-1/2
     const float* x = nullptr;        // [B,N,C]
     const float* slots0 = nullptr;   // [B,K,D]
     const float* wts = nullptr;      // packed weights, sa_wts_layout
     float* slots = nullptr;          // [B,K,D]
-    float* attn = nullptr;           // [B,N,K] (last iteration, pre-eps), may be null
+    float* attn = nullptr;           // [B,N,K] (last iteration, pre-eps; summed over the heads), may be null
+    float* attn_heads = nullptr;     // NH > 1 and attn wanted: [B,N,NH*K] scratch for the per-head maps
     float* save = nullptr;           // [B*I*K, sa_save_layout().ld], may be null for inference
     const float* dslots = nullptr;   // [B,K,D]
     float* dx = nullptr;             // [B,N,C]
@@ -212,8 +216,8 @@ struct SlotAttnArgs {
     // weights and slots0 but not x, so a caller can issue it long before the features exist); 2 = the chain without that launch
     int phase = 0;
 };
-size_t sa_xchg_floats_host(int K, int D);      // per image
-size_t sa_parts_floats_host(int B, int K);
+size_t sa_xchg_floats_host(int K, int D);      // per image; K = num_slots * heads
+size_t sa_parts_floats_host(int B, int K);     // K = num_slots * heads
 int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st);
 
 // generic gather/transposing pack: entry e copies src[rows][cols] to dst + dst_off (transposed if requested)

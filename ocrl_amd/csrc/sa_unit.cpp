@@ -17,11 +17,11 @@ namespace {
 struct Lay {
     size_t wts, save, grows, small, table, xchg, parts, scratch, scratch_floats, total;
 };
-Lay layout(int B, int K, int D, int H, int I) {
+Lay layout(int B, int K, int D, int H, int I, int NH) {
     const int C = 64;
     const SaWts wo = sa_wts_layout(C, D, H);
-    const SaSave so = sa_save_layout(C, D, H);
-    const SaGrad go = sa_grad_layout(C, D, H);
+    const SaSave so = sa_save_layout(C, D, H, NH);
+    const SaGrad go = sa_grad_layout(C, D, H, NH);
     Lay l;
     size_t a = 0;
     auto take = [&](size_t n) { size_t r = a; a += (n + 63) & ~(size_t)63; return r; };
@@ -30,8 +30,8 @@ Lay layout(int B, int K, int D, int H, int I) {
     l.grows = take((size_t)B * I * K * go.ld);
     l.small = take((size_t)B * (4 * D + 2 * C));
     l.table = take(64 * sizeof(PackEntry) / 4 + 64);
-    l.xchg = take((size_t)B * sa_xchg_floats_host(K, D));
-    l.parts = take(sa_parts_floats_host(B, K));
+    l.xchg = take((size_t)B * sa_xchg_floats_host(K * NH, D));
+    l.parts = take(sa_parts_floats_host(B, K * NH));
     l.scratch_floats = (size_t)1024 * 3 * D * D / 4 + (1 << 18);
     l.scratch = take(l.scratch_floats);
     l.total = a;
@@ -58,13 +58,28 @@ int tn(const float* dy, int ld_dy, const float* x, int ldx, float* dW, float* db
 
 extern "C" {
 
-size_t ocrl_slot_attention_ws_floats(int B, int K, int D, int H, int I) { return layout(B, K, D, H, I).total; }
+size_t ocrl_slot_attention_ws_floats(int B, int K, int D, int H, int I) { return layout(B, K, D, H, I, 1).total; }
+// heads > 1: + the per-head attention maps [B,N,heads*K] behind the single-head layout
+size_t ocrl_slot_attention_mh_ws_floats(int B, int N, int K, int D, int H, int I, int heads) {
+    return layout(B, K, D, H, I, heads).total + (heads > 1 ? (size_t)B * N * K * heads : 0);
+}
 
 int ocrl_slot_attention_fwd(const float* x, const float* slots0, const float* const* w, float* slots, float* attn, int B, int N, int K, int D, int H, int I,
                             float* ws, size_t ws_floats, void* stream) {
+    return ocrl_slot_attention_mh_fwd(x, slots0, w, slots, attn, B, N, K, D, H, I, 1, ws, ws_floats, stream);
+}
+int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H, int I,
+                            float* ws, size_t ws_floats, void* stream) {
+    return ocrl_slot_attention_mh_bwd(x, dslots, dx, dslots0, dw, B, N, K, D, H, I, 1, ws, ws_floats, stream);
+}
+
+int ocrl_slot_attention_mh_fwd(const float* x, const float* slots0, const float* const* w, float* slots, float* attn, int B, int N, int K, int D, int H, int I,
+                               int NH, float* ws, size_t ws_floats, void* stream) {
     OCRL_REQUIRE(x && slots0 && w && slots && ws, "ocrl_slot_attention_fwd: null argument");
+    OCRL_REQUIRE(NH >= 1 && D % NH == 0, "ocrl_slot_attention_fwd: %d heads do not divide the slot size %d", NH, D);
     const int C = 64;
-    const Lay l = layout(B, K, D, H, I);
+    const Lay l = layout(B, K, D, H, I, NH);
+    OCRL_REQUIRE(ws_floats >= l.total + (NH > 1 ? (size_t)B * N * K * NH : 0), "ocrl_slot_attention_fwd: workspace too small");
     OCRL_REQUIRE(ws_floats >= l.total, "ocrl_slot_attention_fwd: workspace too small (%zu < %zu floats)", ws_floats, l.total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const SaWts wo = sa_wts_layout(C, D, H);
@@ -90,24 +105,25 @@ int ocrl_slot_attention_fwd(const float* x, const float* slots0, const float* co
     if (H * D > mx) mx = H * D;
     RC(pack_launch(reinterpret_cast<const PackEntry*>(ws + l.table), n, mx, ws + l.wts, st));
     SlotAttnArgs a;
-    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
-    a.x = x; a.slots0 = slots0; a.wts = ws + l.wts; a.slots = slots; a.attn = attn; a.save = ws + l.save;
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.NH = NH; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)(D / NH));
+    a.x = x; a.slots0 = slots0; a.wts = ws + l.wts; a.slots = slots; a.attn = attn; a.attn_heads = NH > 1 ? ws + l.total : nullptr; a.save = ws + l.save;
     a.xchg = ws + l.xchg; a.parts = ws + l.parts;
     return slot_attn_launch(a, 0, st);
 }
 
-int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H, int I,
-                            float* ws, size_t ws_floats, void* stream) {
+int ocrl_slot_attention_mh_bwd(const float* x, const float* dslots, float* dx, float* dslots0, float* const* dw, int B, int N, int K, int D, int H, int I,
+                               int NH, float* ws, size_t ws_floats, void* stream) {
     OCRL_REQUIRE(x && dslots && dx && dslots0 && dw && ws, "ocrl_slot_attention_bwd: null argument");
+    OCRL_REQUIRE(NH >= 1 && D % NH == 0, "ocrl_slot_attention_bwd: %d heads do not divide the slot size %d", NH, D);
     const int C = 64;
-    const Lay l = layout(B, K, D, H, I);
+    const Lay l = layout(B, K, D, H, I, NH);
     OCRL_REQUIRE(ws_floats >= l.total, "ocrl_slot_attention_bwd: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const SaSave so = sa_save_layout(C, D, H);
-    const SaGrad go = sa_grad_layout(C, D, H);
+    const SaSave so = sa_save_layout(C, D, H, NH);
+    const SaGrad go = sa_grad_layout(C, D, H, NH);
     float *save = ws + l.save, *grows = ws + l.grows, *small = ws + l.small, *scr = ws + l.scratch;
     SlotAttnArgs a;
-    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.NH = NH; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)(D / NH));
     a.x = x; a.wts = ws + l.wts; a.save = save; a.dslots = dslots; a.dx = dx; a.dslots0 = dslots0; a.grows = grows; a.g_small = small;
     a.xchg = ws + l.xchg; a.parts = ws + l.parts;
     RC(slot_attn_launch(a, 1, st));
@@ -117,9 +133,11 @@ int ocrl_slot_attention_bwd(const float* x, const float* dslots, float* dx, floa
     RC(tn(grows + go.hid, go.ld, save + so.m, so.ld, dw[13], dw[14], R, H, D, 1.f, scr, sf, st));          // mlp.0
     RC(tn(grows + go.gi, go.ld, save + so.u, so.ld, dw[9], dw[11], R, 3 * D, D, 1.f, scr, sf, st));        // gru ih
     RC(tn(grows + go.gh, go.ld, save + so.sprev, so.ld, dw[10], dw[12], R, 3 * D, D, 1.f, scr, sf, st));   // gru hh
-    RC(tn(grows + go.u, go.ld, save + so.up, so.ld, dw[8], nullptr, R, D, C, 1.f, scr, sf, st));           // project_v
     RC(tn(grows + go.q, go.ld, save + so.sn, so.ld, dw[6], nullptr, R, D, D, 1.f, scr, sf, st));           // project_q
-    RC(tn(save + so.q, so.ld, grows + go.qp, go.ld, dw[7], nullptr, R, D, C, a.scale, scr, sf, st));       // project_k
+    for (int h = 0, dh = D / NH; h < NH; ++h) {       // head h: rows h*dh .. of project_v / project_k against that head's means / folded-query gradients
+        RC(tn(grows + go.u + h * dh, go.ld, save + so.up + h * C, so.ld, dw[8] + (size_t)h * dh * C, nullptr, R, dh, C, 1.f, scr, sf, st));           // project_v
+        RC(tn(save + so.q + h * dh, so.ld, grows + go.qp + h * C, go.ld, dw[7] + (size_t)h * dh * C, nullptr, R, dh, C, a.scale, scr, sf, st));       // project_k
+    }
     // LayerNorm gammas / betas: per-image partials [B][ln_s (2D) | ln_m (2D) | ln_in (2C)]; weight and bias are separate tensors here
     const int SM = 4 * D + 2 * C;
     RC(colsum_launch(small + 0, SM, dw[2], B, D, 0, 1.f, scr, sf, st));

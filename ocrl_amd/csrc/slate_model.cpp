@@ -30,7 +30,7 @@ static std::string fmt(const char* f, ...) {
 SlateModel::SlateModel(const SlateConfig& c) : cfg(c) {
     S = c.obs_size; E = S / 4; T = E * E; N = S * S; V = c.vocab; d = c.d_model; C = c.cnn_hidden;
     K = c.num_slots; I = c.num_iters; D = c.slot_size; H = c.mlp_hidden; NB = c.num_blocks; NH = c.num_heads;
-    DH = d / NH; Bmax = c.max_batch;
+    DH = d / NH; Bmax = c.max_batch; SH = c.slot_heads > 0 ? c.slot_heads : 1;
     const int ch = c.obs_channels;
     auto add = [&](const std::string& name, std::vector<int> shp, int g) {
         ParamInfo p;
@@ -160,15 +160,16 @@ void SlateModel::layout_workspace(bool commit) {
     h1_ = carve("sa_mlp_hidden", BN * 64); x_ = carve("sa_inputs", BN * 64);
     slots0_ = carve("slots0", BK * D); slot_noise_ = carve(nullptr, BK * D); slots_ = carve("slots", BK * D);
     attn_ = carve("attn", BN * K);
-    const SaSave so = sa_save_layout(C, D, H);
-    const SaGrad go = sa_grad_layout(C, D, H);
+    attn_heads_ = SH > 1 ? carve(nullptr, BN * K * SH) : nullptr;
+    const SaSave so = sa_save_layout(C, D, H, SH);
+    const SaGrad go = sa_grad_layout(C, D, H, SH);
     const SaWts wo = sa_wts_layout(C, D, H);
     sa_save_ = carve("sa_save", BK * I * so.ld);
     sa_grows_ = carve(nullptr, BK * I * go.ld);
     sa_wts_ = carve(nullptr, wo.total);
     sa_small_ = carve(nullptr, B * (4 * D + 2 * C));
-    sa_xchg_ = carve(nullptr, B * sa_xchg_floats_host(K, D));
-    sa_parts_ = carve(nullptr, sa_parts_floats_host((int)B, K));
+    sa_xchg_ = carve(nullptr, B * sa_xchg_floats_host(K * SH, D));
+    sa_parts_ = carve(nullptr, sa_parts_floats_host((int)B, K * SH));
     sa_pack_dev_ = reinterpret_cast<PackEntry*>(carve(nullptr, 64 * sizeof(PackEntry) / 4 + 64));
     for (int i = 0; i < 4; ++i) {
         const int cin = i == 0 ? 8 : 64;
@@ -463,8 +464,8 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae)
     // path of the decoder)
     RC(slot_init_launch(P("_slotattn.slot_mu"), P("_slotattn.slot_log_sigma"), in.noise_slots, slots0_, B * K, D, in.seed, st, in.seed_dev));
     SlotAttnArgs a;
-    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
-    a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.save = sa_save_;
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.NH = SH; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)(D / SH));
+    a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.attn_heads = attn_heads_; a.save = sa_save_;
     a.xchg = sa_xchg_; a.parts = sa_parts_;
     a.phase = 1;
     RC(slot_attn_launch(a, 0, st));
@@ -959,11 +960,11 @@ int SlateModel::bwd_decoder(hipStream_t st) {
 int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
     const int B = last_.B;
     const long long BN = (long long)B * N, R = (long long)B * I * K;
-    const SaSave so = sa_save_layout(C, D, H);
-    const SaGrad go = sa_grad_layout(C, D, H);
+    const SaSave so = sa_save_layout(C, D, H, SH);
+    const SaGrad go = sa_grad_layout(C, D, H, SH);
     const std::string sa = "_slotattn.slot_attention.";
     SlotAttnArgs a;
-    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)D);
+    a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.NH = SH; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)(D / SH));
     a.x = x_; a.wts = sa_wts_; a.save = sa_save_; a.dslots = gslots_; a.dx = gA_; a.dslots0 = gslots0_; a.grows = sa_grows_; a.g_small = sa_small_;
     a.xchg = sa_xchg_; a.parts = sa_parts_;
     if (fork_dvae) {
@@ -987,9 +988,11 @@ int SlateModel::bwd_encoder(hipStream_t st, bool fork_dvae) {
     RC(lin_bwd_w(sa_grows_ + go.hid, go.ld, sa_save_ + so.m, so.ld, G(sa + "mlp.0.weight"), G(sa + "mlp.0.bias"), R, H, D, 1.f, sw));
     RC(lin_bwd_w(sa_grows_ + go.gi, go.ld, sa_save_ + so.u, so.ld, G(sa + "gru.weight_ih"), G(sa + "gru.bias_ih"), R, 3 * D, D, 1.f, sw));
     RC(lin_bwd_w(sa_grows_ + go.gh, go.ld, sa_save_ + so.sprev, so.ld, G(sa + "gru.weight_hh"), G(sa + "gru.bias_hh"), R, 3 * D, D, 1.f, sw));
-    RC(lin_bwd_w(sa_grows_ + go.u, go.ld, sa_save_ + so.up, so.ld, G(sa + "project_v.weight"), nullptr, R, D, C, 1.f, sw));
     RC(lin_bwd_w(sa_grows_ + go.q, go.ld, sa_save_ + so.sn, so.ld, G(sa + "project_q.weight"), nullptr, R, D, D, 1.f, sw));
-    RC(lin_bwd_w(sa_save_ + so.q, so.ld, sa_grows_ + go.qp, go.ld, G(sa + "project_k.weight"), nullptr, R, D, C, a.scale, sw));
+    for (int h = 0, dh = D / SH; h < SH; ++h) {       // rows of head h of project_v / project_k meet that head's weighted means / folded-query gradients
+        RC(lin_bwd_w(sa_grows_ + go.u + h * dh, go.ld, sa_save_ + so.up + h * C, so.ld, G(sa + "project_v.weight") + (size_t)h * dh * C, nullptr, R, dh, C, 1.f, sw));
+        RC(lin_bwd_w(sa_save_ + so.q + h * dh, so.ld, sa_grows_ + go.qp + h * C, go.ld, G(sa + "project_k.weight") + (size_t)h * dh * C, nullptr, R, dh, C, a.scale, sw));
+    }
     const int SM = 4 * D + 2 * C;
     RC(colsum_launch(sa_small_ + 0, SM, G(sa + "norm_slots.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, sw));
     RC(colsum_launch(sa_small_ + 2 * D, SM, G(sa + "norm_mlp.weight"), B, 2 * D, 0, 1.f, scratch_, scratch_floats_, sw));

@@ -15,6 +15,7 @@ struct SlateConfig {
     int max_batch = 1;
     int use_bcdec = 0;      // Slot-Attention configuration: spatial-broadcast decoder instead of dVAE + transformer
     int hard = 0;           // ocr_config.hard: straight-through Gumbel sample for the dVAE decoder (utils.py:81-83)
+    int slot_heads = 1;     // ocr_config.slotattr.num_slot_heads (ocrs/common/slot_attn.py:28)
 };
 
 struct ParamInfo {
@@ -110,6 +111,7 @@ private:
 
     // dims
     int S, E, T, N, V, d, C, K, I, D, H, NB, NH, DH, Bmax;
+    int SH = 1;             // slot-attention heads
     // last step
     StepInputs last_;
     float pdrop_ = 0.f;
@@ -132,6 +134,7 @@ private:
     float *dd0_, *dd1_, *dd2_, *dd3_, *dd4_, *ps1_, *dd6_, *dd7_, *dd8_, *dd9_, *ps2_, *recon_, *drecon_;
     float *e1_, *e2_, *e3_, *e4_, *posmap_, *gridT_, *ln0_, *ln0_mean_, *ln0_rstd_, *h1_, *x_;
     float *slots0_, *slot_noise_, *slots_, *attn_, *sa_save_, *sa_wts_, *sa_grows_, *sa_small_, *sa_xchg_;
+    float* attn_heads_ = nullptr;         // [B,N,SH*K] per-head attention maps (SH > 1 only)
     float* sa_parts_;
     PackEntry* sa_pack_dev_ = nullptr;
     int sa_pack_n_ = 0, sa_pack_max_ = 0;

@@ -444,8 +444,10 @@ __device__ inline void rows_get(float* lds, const SaRowMap& m, int off, int r0, 
 template <int K, int G>
 struct SaFwdLds {
     float *s, *sn, *q, *u, *gi, *gh, *hid, *qp, *up, *qg, *cs, *qb;
-    __device__ SaFwdLds(float* sm, int D, int H) {
-        constexpr int C = SA_C, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+    // NH heads: the C-wide per-row fields exist per (head, row); virtual row v = h * KP + r, NH * KP <= 16
+    __device__ SaFwdLds(float* sm, int D, int H, int NH) {
+        constexpr int C = SA_C, KB = SaGeo<K, G>::KB;
+        const int KP = SaGeo<K, G>::KP, KV = NH * KP;
         s = sm;                       // [KP][D] slots (rows beyond the valid ones are padding)
         sn = s + KP * D;              // [KB][D]
         q = sn + KB * D;              // [KB][D]
@@ -453,19 +455,21 @@ struct SaFwdLds {
         gi = u + KB * D;              // [KB][3D]
         gh = gi + KB * 3 * D;         // [KB][3D]
         hid = gh + KB * 3 * D;        // [KB][H]
-        qp = hid + KB * H;            // [KP][C]
-        up = qp + KP * C;             // [KP][C]
-        qg = up + KP * C;             // [KP][C] gamma_in * q'
-        cs = qg + KP * C;             // [16] weight sums
+        qp = hid + KB * H;            // [KV][C]
+        up = qp + KV * C;             // [KV][C]
+        qg = up + KV * C;             // [KV][C] gamma_in * q'
+        cs = qg + KV * C;             // [16] weight sums
         qb = cs + 16;                 // [16] beta_in . q'
     }
 };
+// rows per image of the exchange buffers as the streaming kernels see them (SaBlk<KS>::KP for KS = heads * slots columns)
+__host__ __device__ inline int sa_ki(int KS) { return KS > 8 ? 2 * ((KS + 1) / 2) : KS; }
 
 // slot side before the streaming pass of iteration t: LN(slots), q, q' = scale q Wk, and q' folded with the norm_inputs affine
 template <int K, int G>
 __device__ __forceinline__ void sa_phase_a(const SaFwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaRowMap& sv, int nvalid) {
     constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
-    const int D = p.D;
+    const int D = p.D, NH = p.NH, dh = D / NH;
     const float* W = p.wts;
 #pragma unroll 1
     for (int hb = 0; hb < NB; ++hb) {
@@ -475,15 +479,17 @@ __device__ __forceinline__ void sa_phase_a(const SaFwdLds<K, G>& L, const SlotAt
         ln_rows(sB, L.sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
         __syncthreads();
         matvec<KB>(W + wo.Wq, D, D, D, L.sn, D, L.q, D, nullptr, 1.f);
-        matvec<KB>(W + wo.WkT, D, D, C, L.q, D, L.qp + j0 * C, C, nullptr, p.scale);
+        // q'_h = scale q[:, head h] Wk[head h, :]  (one head: the whole row)
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) matvec<KB>(W + wo.WkT + h * dh, D, dh, C, L.q + h * dh, D, L.qp + (h * KP + j0) * C, C, nullptr, p.scale);
         if (sv.base) {
             rows_put(L.sn, sv, so.sn, j0, kv, D);
             rows_put(L.q, sv, so.q, j0, kv, D);
-            rows_put(L.qp + j0 * C, sv, so.qp, j0, kv, C);
+            for (int h = 0; h < NH; ++h) rows_put(L.qp + (h * KP + j0) * C, sv, so.qp + h * C, j0, kv, C);
         }
         __syncthreads();
     }
-    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, KP);
+    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, NH * KP);
     __syncthreads();
 }
 
@@ -507,36 +513,44 @@ template <int K, int G>
 __device__ __forceinline__ void sa_reduce_parts(const SaFwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, int b0, int NS,
                                                 const SaRowMap& sv, int nvalid) {
     constexpr int C = SA_C, KP = SaGeo<K, G>::KP;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x, nt = blockDim.x, NH = p.NH, KV = NH * KP;
     const float* W = p.wts;
-    const int pstride = K * (C + 1);
-    if (tid < nvalid) L.cs[tid] = sa_psum(p.parts + (size_t)(b0 + tid / K) * NS * pstride, NS, pstride, (tid % K) * (C + 1) + C);
+    const int pstride = NH * K * (C + 1);          // an image's partial: [NH*K columns][65], column = head * K + slot
+    if (tid < KV) {
+        const int h = tid / KP, r = tid - h * KP;
+        if (r < nvalid) L.cs[tid] = sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (h * K + r % K) * (C + 1) + C);
+    }
     __syncthreads();
-    for (int i = tid; i < KP * C; i += nt) {
-        const int r = i >> 6, c = i & 63;
+    for (int i = tid; i < KV * C; i += nt) {
+        const int v_ = i >> 6, c = i & 63, h = v_ / KP, r = v_ - h * KP;
         if (r >= nvalid) { L.up[i] = 0.f; continue; }
-        float a = sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (r % K) * (C + 1) + c);
-        a /= L.cs[r];                                                  // sum_n w xn / sum_n w
+        float a = sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (h * K + r % K) * (C + 1) + c);
+        a /= L.cs[v_];                                                 // sum_n w xn / sum_n w
         const float v = a * W[wo.ln_in_g + c] + W[wo.ln_in_b + c];
         L.up[i] = v;
-        if (sv.base) { float* row = sv(r); row[so.upn + c] = a; row[so.up + c] = v; }
+        if (sv.base) { float* row = sv(r); row[so.upn + h * C + c] = a; row[so.up + h * C + c] = v; }
     }
-    if (sv.base && tid < nvalid) sv(tid)[so.csum] = L.cs[tid];
+    if (sv.base && tid < KV) {
+        const int h = tid / KP, r = tid - h * KP;
+        if (r < nvalid) sv(r)[so.csum + h] = L.cs[tid];
+    }
     __syncthreads();
 }
 
 // slot side after the streaming pass: updates = U' Wv^T ; GRU ; residual MLP
 template <int K, int G>
 __device__ __forceinline__ void sa_phase_u(const SaFwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaRowMap& sv, int nvalid) {
-    constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB;
-    const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x;
+    constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+    const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x, NH = p.NH, dh = D / NH;
     const float* W = p.wts;
     float *q = L.q, *u = L.u, *gi = L.gi, *gh = L.gh, *hid = L.hid, *sn = L.sn;
 #pragma unroll 1
     for (int hb = 0; hb < NB; ++hb) {
         const int j0 = hb * KB, kv = (nvalid - j0) < KB ? (nvalid - j0 > 0 ? nvalid - j0 : 0) : KB;
         float* sB = L.s + j0 * D;
-        matvec<KB>(W + wo.Wv, C, C, D, L.up + j0 * C, C, u, D, nullptr, 1.f);
+        // updates[:, head h] = U'_h Wv[head h, :]^T
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) matvec<KB>(W + wo.Wv + h * dh * C, C, C, dh, L.up + (h * KP + j0) * C, C, u + h * dh, D, nullptr, 1.f);
         {
             const MvJob ji = {W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f}, jh = {W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f};
             matvec2<KB>(ji, jh);
@@ -613,12 +627,12 @@ __global__ __launch_bounds__(SA_TS, V2 ? 4 : 3) void sa_stream_fwd_kernel(SlotAt
 template <int K, int G>
 __global__ __launch_bounds__(SA_TF) void sa_slot_fwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, int t, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int C = SA_C, KP = SaGeo<K, G>::KP, KI = SaGeo<K, G>::KI;
-    const int D = p.D, nt = blockDim.x, tid = threadIdx.x;
-    const SaFwdLds<K, G> L(sm, D, p.H);
+    constexpr int C = SA_C, KP = SaGeo<K, G>::KP;
+    const int D = p.D, nt = blockDim.x, tid = threadIdx.x, NH = p.NH, KI = sa_ki(NH * K);
+    const SaFwdLds<K, G> L(sm, D, p.H, NH);
     const int b0 = blockIdx.x * G;
     const int nimg = (p.B - b0) < G ? (p.B - b0) : G, nvalid = nimg * K;
-    const size_t XF = sa_xchg_floats(K, D);
+    const size_t XF = sa_xchg_floats(NH * K, D);
     float* xg0 = p.xchg + (size_t)b0 * XF;
     float* save = p.save;
     if (t < 0) {
@@ -641,8 +655,14 @@ __global__ __launch_bounds__(SA_TF) void sa_slot_fwd_kernel(SlotAttnArgs p, SaWt
         sa_phase_a<K, G>(L, p, wo, so, sa_rows(save, so.ld, b0, t + 1, p.I, K), nvalid);
     }
     for (int i = tid; i < nvalid * D; i += nt) { const int r = i / D, c = i - r * D; xg0[(size_t)(r / K) * XF + (r % K) * D + c] = L.s[i]; }
-    for (int i = tid; i < nvalid * C; i += nt) { const int r = i >> 6, c = i & 63; xg0[(size_t)(r / K) * XF + KI * D + (r % K) * C + c] = L.qg[i]; }
-    if (tid < nvalid) xg0[(size_t)(tid / K) * XF + KI * D + KI * C + tid % K] = L.qb[tid];
+    for (int i = tid; i < NH * KP * C; i += nt) {
+        const int v = i >> 6, c = i & 63, h = v / KP, r = v - h * KP;
+        if (r < nvalid) xg0[(size_t)(r / K) * XF + KI * D + (h * K + r % K) * C + c] = L.qg[i];
+    }
+    if (tid < NH * KP) {
+        const int h = tid / KP, r = tid - h * KP;
+        if (r < nvalid) xg0[(size_t)(r / K) * XF + KI * D + KI * C + h * K + r % K] = L.qb[tid];
+    }
 }
 
 // ------------------------------------------------------------------------------------------- backward streaming pass
@@ -956,8 +976,9 @@ __device__ __forceinline__ void sa_stream_bwd2(const float4* __restrict__ xb, fl
 template <int K, int G>
 struct SaBwdLds {
     float *ds, *t2, *t0, *t1, *dgi, *dgh, *dhid, *qp, *dup, *dqp, *qg, *dug, *cs, *ud, *qb, *dub, *sdl, *gacc;
-    __device__ SaBwdLds(float* sm, int D, int H) {
+    __device__ SaBwdLds(float* sm, int D, int H, int NH) {
         constexpr int C = SA_C, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
+        const int KV = NH * KP;          // virtual rows (head, row) of the C-wide fields
         ds = sm;                      // [KP][D] gradient wrt the iteration output
         t2 = ds + KP * D;             // [KP][D] dh (direct GRU path), kept across the streaming pass
         t0 = t2 + KP * D;             // [KB][D] scratch
@@ -965,12 +986,12 @@ struct SaBwdLds {
         dgi = t1 + KB * D;            // [KB][3D]
         dgh = dgi + KB * 3 * D;       // [KB][3D]
         dhid = dgh + KB * 3 * D;      // [KB][H]
-        qp = dhid + KB * H;           // [KP][C]
-        dup = qp + KP * C;            // [KP][C]
-        dqp = dup + KP * C;           // [KP][C]
-        qg = dqp + KP * C;            // [KP][C] gamma_in * q'
-        dug = qg + KP * C;            // [KP][C] gamma_in * dU'
-        cs = dug + KP * C;            // [16] csum
+        qp = dhid + KB * H;           // [KV][C]
+        dup = qp + KV * C;            // [KV][C]
+        dqp = dup + KV * C;           // [KV][C]
+        qg = dqp + KV * C;            // [KV][C] gamma_in * q'
+        dug = qg + KV * C;            // [KV][C] gamma_in * dU'
+        cs = dug + KV * C;            // [16] csum
         ud = cs + 16;                 // [16] up . dup
         qb = ud + 16;                 // [16] beta_in . q'
         dub = qb + 16;                // [16] beta_in . dU'
@@ -985,7 +1006,7 @@ template <int K, int G>
 __device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaGrad& go,
                                              const SaRowMap& sv, const SaRowMap& gr, int nvalid) {
     constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
-    const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x;
+    const int D = p.D, H = p.H, tid = threadIdx.x, nt = blockDim.x, NH = p.NH, dh = D / NH, KV = NH * KP;
     const float* W = p.wts;
     float* dg_m = L.gacc + 2 * D;  float* db_m = L.gacc + 3 * D;
 #pragma unroll 1
@@ -1032,21 +1053,27 @@ __device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const Slot
         for (int i = tid; i < kv * D; i += nt) t2B[i] += t0[i];
         rows_put(t1, gr, go.u, j0, kv, D);
         // ---- u = up Wv^T
-        matvec<KB>(W + wo.WvT, D, D, C, t1, D, L.dup + j0 * C, C, nullptr, 1.f);   // dup[c] = sum_d du[d] Wv[d][c]
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h)          // dU'_h[c] = sum_{d in head h} du[d] Wv[d][c]
+            matvec<KB>(W + wo.WvT + h * dh, D, dh, C, t1 + h * dh, D, L.dup + (h * KP + j0) * C, C, nullptr, 1.f);
     }
-    rows_get(L.qp, sv, so.qp, 0, nvalid, C);
-    for (int i = nvalid * C + tid; i < KP * C; i += nt) { L.qp[i] = 0.f; L.dup[i] = 0.f; }
+    for (int h = 0; h < NH; ++h) rows_get(L.qp + h * KP * C, sv, so.qp + h * C, 0, nvalid, C);
+    for (int i = tid; i < KV * C; i += nt)
+        if (((i >> 6) % KP) >= nvalid) { L.qp[i] = 0.f; L.dup[i] = 0.f; }
     __syncthreads();
-    if (tid < nvalid) {
-        const float* row = sv(tid);
-        L.cs[tid] = row[so.csum];
-        float a = 0.f;
-        for (int c = 0; c < C; ++c) a += row[so.up + c] * L.dup[tid * C + c];
-        L.ud[tid] = a;
+    if (tid < KV) {
+        const int h = tid / KP, r = tid - h * KP;
+        if (r < nvalid) {
+            const float* row = sv(r);
+            L.cs[tid] = row[so.csum + h];
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) a += row[so.up + h * C + c] * L.dup[tid * C + c];
+            L.ud[tid] = a;
+        }
     }
     __syncthreads();
-    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, KP);
-    sa_fold_affine(L.dup, W + wo.ln_in_g, W + wo.ln_in_b, L.dug, L.dub, KP);
+    sa_fold_affine(L.qp, W + wo.ln_in_g, W + wo.ln_in_b, L.qg, L.qb, KV);
+    sa_fold_affine(L.dup, W + wo.ln_in_g, W + wo.ln_in_b, L.dug, L.dub, KV);
     __syncthreads();
 }
 
@@ -1056,41 +1083,48 @@ template <int K, int G>
 __device__ __forceinline__ void sa_bwd_part2(const SaBwdLds<K, G>& L, const SlotAttnArgs& p, const SaWts& wo, const SaSave& so, const SaGrad& go,
                                              const SaRowMap& sv, const SaRowMap& gr, int b0, int NS, int nvalid) {
     constexpr int C = SA_C, NB = SaGeo<K, G>::NB, KB = SaGeo<K, G>::KB, KP = SaGeo<K, G>::KP;
-    const int D = p.D, tid = threadIdx.x, nt = blockDim.x;
+    const int D = p.D, tid = threadIdx.x, nt = blockDim.x, NH = p.NH, dh = D / NH, KV = NH * KP;
     const float* W = p.wts;
     float* dg_s = L.gacc;  float* db_s = L.gacc + D;
     float* dg_in = L.gacc + 4 * D;  float* db_in = L.gacc + 4 * D + C;
     float *dqp = L.dqp, *sdl = L.sdl, *t0 = L.t0, *t1 = L.t1;
-    const int pstride = K * (C + 1);
-    if (tid < nvalid) sdl[tid] = sa_psum(p.parts + (size_t)(b0 + tid / K) * NS * pstride, NS, pstride, (tid % K) * (C + 1) + C);
-    for (int i = tid; i < KP * C; i += nt) {
-        const int r = i >> 6, c = i & 63;
-        dqp[i] = r < nvalid ? sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (r % K) * (C + 1) + c) : 0.f;   // sum_n dl xn (pre-affine)
+    const int pstride = NH * K * (C + 1);
+    if (tid < KV) {
+        const int h = tid / KP, r = tid - h * KP;
+        sdl[tid] = r < nvalid ? sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (h * K + r % K) * (C + 1) + C) : 0.f;
+    }
+    for (int i = tid; i < KV * C; i += nt) {
+        const int v = i >> 6, c = i & 63, h = v / KP, r = v - h * KP;
+        dqp[i] = r < nvalid ? sa_psum(p.parts + (size_t)(b0 + r / K) * NS * pstride, NS, pstride, (h * K + r % K) * (C + 1) + c) : 0.f;   // sum_n dl xn (pre-affine)
     }
     __syncthreads();
     // norm_inputs gamma/beta:  d xa = wn dU' + dl q'  =>  dgamma = sum_j dU' upn + q' dqn,  dbeta = sum_j dU' + q' sdl
     if (tid < C) {
         float dg = 0.f, db = 0.f;
-        for (int j = 0; j < nvalid; ++j) {
-            dg += L.dup[j * C + tid] * sv(j)[so.upn + tid] + L.qp[j * C + tid] * dqp[j * C + tid];
-            db += L.dup[j * C + tid] + L.qp[j * C + tid] * sdl[j];
-        }
+        for (int h = 0; h < NH; ++h)
+            for (int r = 0; r < nvalid; ++r) {
+                const int j = h * KP + r;
+                dg += L.dup[j * C + tid] * sv(r)[so.upn + h * C + tid] + L.qp[j * C + tid] * dqp[j * C + tid];
+                db += L.dup[j * C + tid] + L.qp[j * C + tid] * sdl[j];
+            }
         dg_in[tid] += dg;
         db_in[tid] += db;
     }
     __syncthreads();
-    for (int i = tid; i < nvalid * C; i += nt) {
+    for (int i = tid; i < KV * C; i += nt) {
         const int j = i >> 6, c = i & 63;
-        dqp[i] = dqp[i] * W[wo.ln_in_g + c] + W[wo.ln_in_b + c] * sdl[j];   // d q' = sum_n dl LN(x)
+        if ((j % KP) < nvalid) dqp[i] = dqp[i] * W[wo.ln_in_g + c] + W[wo.ln_in_b + c] * sdl[j];   // d q' = sum_n dl LN(x)
     }
     __syncthreads();
-    rows_put(dqp, gr, go.qp, 0, nvalid, C);
+    for (int h = 0; h < NH; ++h) rows_put(dqp + h * KP * C, gr, go.qp + h * C, 0, nvalid, C);
 #pragma unroll 1
     for (int hb = 0; hb < NB; ++hb) {
         const int j0 = hb * KB, kv = (nvalid - j0) < KB ? (nvalid - j0 > 0 ? nvalid - j0 : 0) : KB;
         float* dsB = L.ds + j0 * D;
         // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
-        matvec<KB>(W + wo.Wk, C, C, D, dqp + j0 * C, C, t1, D, nullptr, p.scale);   // t1 = dq
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h)          // dq[:, head h] = scale dq'_h Wk[head h, :]^T
+            matvec<KB>(W + wo.Wk + h * dh * C, C, C, dh, dqp + (h * KP + j0) * C, C, t1 + h * dh, D, nullptr, p.scale);   // t1 = dq
         rows_put(t1, gr, go.q, j0, kv, D);
         rows_get(t0, sv, so.sprev, j0, kv, D);
         for (int i = kv * D + tid; i < KB * D; i += nt) t0[i] = 0.f;
@@ -1115,12 +1149,12 @@ template <int K, int G>
 __global__ __launch_bounds__(SA_TB) void sa_slot_bwd_kernel(SlotAttnArgs p, SaWts wo, SaSave so, SaGrad go, int t_hi, int t_lo, int NS) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int D = p.D;
-    constexpr int C = SA_C, KP = SaGeo<K, G>::KP, KI = SaGeo<K, G>::KI;
-    const int nt = blockDim.x, tid = threadIdx.x;
-    const SaBwdLds<K, G> L(sm, D, p.H);
+    constexpr int C = SA_C, KP = SaGeo<K, G>::KP;
+    const int nt = blockDim.x, tid = threadIdx.x, NH = p.NH, KV = NH * KP, KI = sa_ki(NH * K);
+    const SaBwdLds<K, G> L(sm, D, p.H, NH);
     const int b0 = blockIdx.x * G;
     const int nimg = (p.B - b0) < G ? (p.B - b0) : G, nvalid = nimg * K;
-    const size_t XF = sa_xchg_bwd_floats(K, D);
+    const size_t XF = sa_xchg_bwd_floats(NH * K, D);
     float* xg0 = p.xchg + (size_t)b0 * XF;
     const int SM = 4 * D + 2 * C;
     float* gs = p.g_small + (size_t)b0 * SM;
@@ -1129,10 +1163,14 @@ __global__ __launch_bounds__(SA_TB) void sa_slot_bwd_kernel(SlotAttnArgs p, SaWt
         for (int i = tid; i < SM; i += nt) L.gacc[i] = 0.f;
     } else {
         for (int i = tid; i < KP * D; i += nt) { const int r = i / D, c = i - r * D; L.t2[i] = r < nvalid ? xg0[(size_t)(r / K) * XF + (r % K) * D + c] : 0.f; }
-        for (int i = tid; i < KP * C; i += nt) { const int r = i >> 6, c = i & 63; L.dup[i] = r < nvalid ? xg0[(size_t)(r / K) * XF + KI * D + (r % K) * C + c] : 0.f; }
+        for (int i = tid; i < KV * C; i += nt) {
+            const int v = i >> 6, c = i & 63, h = v / KP, r = v - h * KP;
+            L.dup[i] = r < nvalid ? xg0[(size_t)(r / K) * XF + KI * D + (h * K + r % K) * C + c] : 0.f;
+        }
         for (int i = tid; i < SM; i += nt) L.gacc[i] = gs[i];
-        rows_get(L.qp, sa_rows(p.save, so.ld, b0, t_hi, p.I, K), so.qp, 0, nvalid, C);
-        for (int i = nvalid * C + tid; i < KP * C; i += nt) L.qp[i] = 0.f;
+        for (int h = 0; h < NH; ++h) rows_get(L.qp + h * KP * C, sa_rows(p.save, so.ld, b0, t_hi, p.I, K), so.qp + h * C, 0, nvalid, C);
+        for (int i = tid; i < KV * C; i += nt)
+            if (((i >> 6) % KP) >= nvalid) L.qp[i] = 0.f;
     }
     __syncthreads();
     if (t_hi >= 0)
@@ -1140,14 +1178,18 @@ __global__ __launch_bounds__(SA_TB) void sa_slot_bwd_kernel(SlotAttnArgs p, SaWt
     if (t_lo >= 0) {
         sa_bwd_part1<K, G>(L, p, wo, so, go, sa_rows(p.save, so.ld, b0, t_lo, p.I, K), sa_rows(p.grows, go.ld, b0, t_lo, p.I, K), nvalid);
         for (int i = tid; i < nvalid * D; i += nt) { const int r = i / D, c = i - r * D; xg0[(size_t)(r / K) * XF + (r % K) * D + c] = L.t2[i]; }
-        for (int i = tid; i < nvalid * C; i += nt) {
-            const int r = i >> 6, c = i & 63;
-            float* x = xg0 + (size_t)(r / K) * XF + KI * D + (r % K) * C + c;
+        for (int i = tid; i < KV * C; i += nt) {
+            const int v = i >> 6, c = i & 63, h = v / KP, r = v - h * KP;
+            if (r >= nvalid) continue;
+            float* x = xg0 + (size_t)(r / K) * XF + KI * D + (h * K + r % K) * C + c;
             x[0] = L.dup[i]; x[KI * C] = L.qg[i]; x[2 * KI * C] = L.dug[i];
         }
-        if (tid < nvalid) {
-            float* x = xg0 + (size_t)(tid / K) * XF + KI * D + 3 * KI * C + tid % K;
-            x[0] = L.qb[tid]; x[16] = L.dub[tid]; x[32] = L.cs[tid]; x[48] = L.ud[tid];
+        if (tid < KV) {
+            const int h = tid / KP, r = tid - h * KP;
+            if (r < nvalid) {
+                float* x = xg0 + (size_t)(r / K) * XF + KI * D + 3 * KI * C + h * K + r % K;
+                x[0] = L.qb[tid]; x[16] = L.dub[tid]; x[32] = L.cs[tid]; x[48] = L.ud[tid];
+            }
         }
     } else {
         for (int i = tid; i < nvalid * D; i += nt) p.dslots0[(size_t)b0 * K * D + i] = L.ds[i];
@@ -1186,13 +1228,13 @@ __global__ __launch_bounds__(SA_TS, 2) void sa_stream_bwd_kernel(SlotAttnArgs p,
     }
 }
 
-static size_t sa_fwd_smem(int K, int G, int D, int H) {
+static size_t sa_fwd_smem(int K, int G, int D, int H, int NH = 1) {
     const int NB = K > 8 ? 2 : 1, KB = K > 8 ? (K + 1) / 2 : G * K, KP = NB * KB;
-    return (size_t)(KP * D + KB * D * 3 + KB * 3 * D * 2 + KB * H + KP * SA_C * 3 + 32) * 4;
+    return (size_t)(KP * D + KB * D * 3 + KB * 3 * D * 2 + KB * H + NH * KP * SA_C * 3 + 32) * 4;
 }
-static size_t sa_bwd_smem(int K, int G, int D, int H) {
+static size_t sa_bwd_smem(int K, int G, int D, int H, int NH = 1) {
     const int NB = K > 8 ? 2 : 1, KB = K > 8 ? (K + 1) / 2 : G * K, KP = NB * KB;
-    return (size_t)(KP * D * 2 + KB * D * 2 + KB * 3 * D * 2 + KB * H + KP * SA_C * 5 + 80 + 4 * D + 2 * SA_C) * 4;
+    return (size_t)(KP * D * 2 + KB * D * 2 + KB * 3 * D * 2 + KB * H + NH * KP * SA_C * 5 + 80 + 4 * D + 2 * SA_C) * 4;
 }
 #define SA_LDS_MAX (160 * 1024 - 256)       // dynamic LDS available to a workgroup (the kernels hold 128 bytes of static LDS)
 size_t sa_xchg_floats_host(int K, int D) {
@@ -1283,6 +1325,82 @@ static int sa_launch_kg(const SlotAttnArgs& a, int backward, hipStream_t st) {
     OCRL_CHECK_LAUNCH("slot_attn");
     return 0;
 }
+// ---- several attention heads (ocrs/common/slot_attn.py:54-92).  The soft-max runs over heads * K columns and every column has its own
+// folded query and weighted mean, so the streaming kernels are the single-head ones instantiated for KS = heads * K "slots"; the
+// slot-side kernels (one image per workgroup) build / consume the per-head folded operands.  attn_vis = sum over the heads.
+typedef void (*SaStreamFwdFn)(SlotAttnArgs, int, int);
+typedef void (*SaStreamBwdFn)(SlotAttnArgs, int);
+template <int KS> static SaStreamBwdFn sa_stream_bwd_pick(bool first, bool final_) {
+    if (first && final_) return sa_stream_bwd_kernel<KS, true, true, true>;
+    if (first) return sa_stream_bwd_kernel<KS, true, false, true>;
+    if (final_) return sa_stream_bwd_kernel<KS, false, true, true>;
+    return sa_stream_bwd_kernel<KS, false, false, true>;
+}
+static SaStreamFwdFn sa_stream_fwd_fn(int KS) {
+    switch (KS) {
+#define SA_CASE(k) case k: return sa_stream_fwd_kernel<k, true>;
+        SA_CASE(2) SA_CASE(3) SA_CASE(4) SA_CASE(5) SA_CASE(6) SA_CASE(7) SA_CASE(8) SA_CASE(9) SA_CASE(10) SA_CASE(11) SA_CASE(12) SA_CASE(13) SA_CASE(14) SA_CASE(15) SA_CASE(16)
+#undef SA_CASE
+    }
+    return nullptr;
+}
+static SaStreamBwdFn sa_stream_bwd_fn(int KS, bool first, bool final_) {
+    switch (KS) {
+#define SA_CASE(k) case k: return sa_stream_bwd_pick<k>(first, final_);
+        SA_CASE(2) SA_CASE(3) SA_CASE(4) SA_CASE(5) SA_CASE(6) SA_CASE(7) SA_CASE(8) SA_CASE(9) SA_CASE(10) SA_CASE(11) SA_CASE(12) SA_CASE(13) SA_CASE(14) SA_CASE(15) SA_CASE(16)
+#undef SA_CASE
+    }
+    return nullptr;
+}
+__global__ void sa_attn_heads_sum_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows, int K, int NH) {
+    const long long n = rows * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / K; const int k = (int)(i - r * K);
+        float a = 0.f;
+        for (int h = 0; h < NH; ++h) a += in[r * (NH * K) + h * K + k];
+        out[i] = a;
+    }
+}
+template <int K>
+static int sa_launch_heads(const SlotAttnArgs& a0, int backward, hipStream_t st) {
+    const int NH = a0.NH, KS = NH * K, KPS = sa_ki(KS);
+    const size_t smem = backward ? sa_bwd_smem(K, 1, a0.D, a0.H, NH) : sa_fwd_smem(K, 1, a0.D, a0.H, NH);
+    OCRL_REQUIRE(smem <= SA_LDS_MAX, "slot_attn: LDS request %zu too large (num_slots %d, heads %d, slot size %d)", smem, K, NH, a0.D);
+    OCRL_REQUIRE(!a0.attn || a0.attn_heads, "slot_attn: the per-head attention scratch is missing");
+    SlotAttnArgs a = a0;
+    if (a.attn) a.attn = a0.attn_heads;          // the streaming kernel writes [B,N,KS]
+    const SaWts wo = sa_wts_layout(a.C, a.D, a.H);
+    const SaSave so = sa_save_layout(a.C, a.D, a.H, NH);
+    const SaGrad go = sa_grad_layout(a.C, a.D, a.H, NH);
+    OCRL_HIP(hipFuncSetAttribute((const void*)(backward ? (const void*)sa_slot_bwd_kernel<K, 1> : (const void*)sa_slot_fwd_kernel<K, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SA_LDS_MAX));
+    const int NS = sa_splits(a.B, a.N, 4);
+    const int pi = prof_begin(backward ? PROF_SA_BWD : PROF_SA_FWD, st);
+    if (!backward) {
+        const size_t smem_stream = (size_t)(KPS * SA_C + 16 + (SA_TS / 64) * (16 * SA_TLD + 16 * SA_WT_LD)) * 4;
+        const SaStreamFwdFn fs = sa_stream_fwd_fn(KS);
+        if (a.phase != 2) hipLaunchKernelGGL((sa_slot_fwd_kernel<K, 1>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so, -1, NS);
+        for (int t = 0; t < a.I && a.phase != 1; ++t) {
+            hipLaunchKernelGGL(fs, dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, t, NS);
+            hipLaunchKernelGGL((sa_slot_fwd_kernel<K, 1>), dim3(a.B), dim3(SA_TF), smem, st, a, wo, so, t, NS);
+        }
+        if (a0.attn && a.phase != 1) {
+            const long long rows = (long long)a.B * a.N;
+            hipLaunchKernelGGL(sa_attn_heads_sum_kernel, dim3(cdiv(rows * K, 256) > 4096 ? 4096 : cdiv(rows * K, 256)), dim3(256), 0, st, a0.attn_heads, a0.attn, rows, K, NH);
+        }
+    } else {
+        const size_t smem_stream = (size_t)(2 * KPS * SA_C + 64 + (SA_TS / 64) * (16 * SA_TLD + 2 * 16 * SA_WLD)) * 4;
+        hipLaunchKernelGGL((sa_slot_bwd_kernel<K, 1>), dim3(a.B), dim3(SA_TB), smem, st, a, wo, so, go, -1, a.I - 1, NS);
+        for (int t = a.I - 1; t >= 0; --t) {
+            hipLaunchKernelGGL(sa_stream_bwd_fn(KS, t == a.I - 1, t == 0), dim3(a.B * NS), dim3(SA_TS), smem_stream, st, a, NS);
+            hipLaunchKernelGGL((sa_slot_bwd_kernel<K, 1>), dim3(a.B), dim3(SA_TB), smem, st, a, wo, so, go, t, t - 1, NS);
+        }
+    }
+    prof_end(pi, st);
+    OCRL_CHECK_LAUNCH("slot_attn (heads)");
+    return 0;
+}
+
 template <int K>
 static int sa_launch_k(const SlotAttnArgs& a, int backward, hipStream_t st) {
     OCRL_REQUIRE(a.xchg && a.parts, "slot_attn: exchange / partial buffers missing");
@@ -1304,6 +1422,17 @@ int slot_attn_launch(const SlotAttnArgs& a, int backward, hipStream_t st) {
     if (backward) OCRL_REQUIRE(a.dx && ((uintptr_t)a.dx & 15) == 0 && a.save && a.grows && a.dslots && a.dslots0 && a.g_small, "slot_attn bwd: missing buffers");
     else OCRL_REQUIRE(a.slots0 && a.slots, "slot_attn fwd: missing buffers");
     OCRL_REQUIRE(a.xchg && a.parts && ((uintptr_t)a.xchg & 15) == 0, "slot_attn: exchange / partial buffers missing or xchg not 16-byte aligned");
+    OCRL_REQUIRE(a.NH >= 1 && a.D % a.NH == 0, "slot_attn: the slot size %d does not divide into %d heads", a.D, a.NH);
+    if (a.NH > 1) {
+        OCRL_REQUIRE(a.K <= 8 && a.NH * a.K <= 16 && (a.D / a.NH) % 16 == 0,
+                     "slot_attn: with %d heads, heads * num_slots <= 16 and a head width that is a multiple of 16 are supported (num_slots %d, slot size %d)", a.NH, a.K, a.D);
+        switch (a.K) {
+#define SA_CASE(k) case k: return sa_launch_heads<k>(a, backward, st);
+            SA_CASE(1) SA_CASE(2) SA_CASE(3) SA_CASE(4) SA_CASE(5) SA_CASE(6) SA_CASE(7) SA_CASE(8)
+#undef SA_CASE
+        }
+        return -1;
+    }
     switch (a.K) {
 #define SA_CASE(k) case k: return sa_launch_k<k>(a, backward, st);
         SA_CASE(1) SA_CASE(2) SA_CASE(3) SA_CASE(4) SA_CASE(5) SA_CASE(6) SA_CASE(7) SA_CASE(8)

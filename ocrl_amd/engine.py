@@ -34,7 +34,7 @@ class SlateEngine:
         c = _lib.SlateConfig(dims.obs_size, dims.obs_channels, dims.vocab_size, dims.d_model, dims.cnn_hidden, dims.num_slots,
                              dims.num_iterations, dims.slot_size, dims.mlp_hidden, dims.num_dec_blocks, dims.num_dec_heads,
                              float(dims.dropout), self.max_batch, int(bool(getattr(dims, "use_bcdec", False))),
-                             int(bool(getattr(dims, "hard", False))))
+                             int(bool(getattr(dims, "hard", False))), int(getattr(dims, "num_slot_heads", 1)))
         h = ctypes.c_void_p()
         _lib.check(self.L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)))
         self.h = h

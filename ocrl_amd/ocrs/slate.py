@@ -41,17 +41,19 @@ def _dims(ocr_config, env_config):
     sa = ocr_config.slotattr
     heads = int(getattr(sa, "num_slot_heads", 1))
     if heads != 1:
-        # ocrs/common/slot_attn.py:54-92 splits q/k/v into `heads` groups and takes the softmax over heads*slots columns; the HIP
-        # slot-attention kernels implement the single-head form every shipped configuration uses (configs/ocr/slate.yaml:21)
-        raise NotImplementedError(f"ocrl_amd: ocr.slotattr.num_slot_heads={heads} is not supported by the HIP backend (only 1); "
-                                  "the reference's multi-head slot attention (ocrs/common/slot_attn.py:54-92) is not built")
+        # ocrs/common/slot_attn.py:54-92 splits q/k/v into `heads` groups and takes the softmax over heads*slots columns: the HIP
+        # kernels run those columns on the 16 columns of one MFMA tile, which bounds the supported shapes
+        K, D = int(sa.num_slots), int(sa.slot_size)
+        if heads < 1 or K > 8 or heads * K > 16 or D % heads or (D // heads) % 16:
+            raise NotImplementedError(f"ocrl_amd: ocr.slotattr.num_slot_heads={heads} with num_slots={K}, slot_size={D} is not supported by the "
+                                      "HIP backend: heads * num_slots <= 16, num_slots <= 8 and a head width that is a multiple of 16 are")
     return SimpleNamespace(
         obs_size=int(env_config.obs_size), obs_channels=int(env_config.obs_channels),
         vocab_size=int(ocr_config.dvae.vocab_size), d_model=int(ocr_config.dvae.d_model), cnn_hidden=int(ocr_config.cnn.hidden_size),
         num_slots=int(sa.num_slots), num_iterations=int(sa.num_iterations), slot_size=int(sa.slot_size),
         mlp_hidden=int(sa.mlp_hidden_size), num_dec_blocks=int(ocr_config.tfdec.num_dec_blocks),
         num_dec_heads=int(ocr_config.tfdec.num_dec_heads), dropout=float(ocr_config.learning.dropout),
-        use_bcdec=bool(ocr_config.use_bcdec), hard=bool(ocr_config.hard))
+        use_bcdec=bool(ocr_config.use_bcdec), hard=bool(ocr_config.hard), num_slot_heads=heads)
 
 
 def _position_grid(S):
@@ -146,7 +148,8 @@ class SLATE_Module(nn.Module):
         L = _lib.lib()
         d = self._dims
         c = _lib.SlateConfig(d.obs_size, d.obs_channels, d.vocab_size, d.d_model, d.cnn_hidden, d.num_slots, d.num_iterations,
-                             d.slot_size, d.mlp_hidden, d.num_dec_blocks, d.num_dec_heads, d.dropout, 1, int(d.use_bcdec), int(d.hard))
+                             d.slot_size, d.mlp_hidden, d.num_dec_blocks, d.num_dec_heads, d.dropout, 1, int(d.use_bcdec), int(d.hard),
+                             int(getattr(d, "num_slot_heads", 1)))
         h = ctypes.c_void_p()
         _lib.check(L.ocrl_slate_create(ctypes.byref(c), ctypes.byref(h)))
         out = []

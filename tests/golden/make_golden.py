@@ -272,11 +272,21 @@ def main():
     torch.set_num_threads(8)
     tiny = O.default_cfg(obs_size=16, vocab_size=128, d_model=64, slot_size=64, mlp_hidden=64,
                          num_slots=3, num_iterations=2, num_dec_blocks=2)
+    # several slot-attention heads (ocrs/common/slot_attn.py:54-92) at shapes the HIP engine runs too: 6 slots x 2 heads (head width 96)
+    # and 4 slots x 4 heads (48); one update() and the next forward / backward, as the a64 case
+    heads2 = O.default_cfg(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2, num_slot_heads=2)
+    heads4 = O.default_cfg(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, num_slot_heads=4)
+    if "--only-heads" in sys.argv:          # the other fixtures stay as committed
+        run_case("heads2_eval", heads2, B=2, seed=11, train_dropout=False, n_steps=1, SLATE=SLATE, full=False)
+        run_case("heads4_eval", heads4, B=3, seed=13, train_dropout=False, n_steps=1, SLATE=SLATE, full=False)
+        return
     run_case("tiny_eval", tiny, B=2, seed=3, train_dropout=False, n_steps=2, SLATE=SLATE, full=True)
     run_case("tiny_train", tiny, B=2, seed=5, train_dropout=True, n_steps=2, SLATE=SLATE, full=False)
     a64 = O.default_cfg(obs_size=64, num_slots=6)
     run_case("a64_eval", a64, B=2, seed=7, train_dropout=False, n_steps=1, SLATE=SLATE, full=False)
     run_bcdec(SLATE)
+    run_case("heads2_eval", heads2, B=2, seed=11, train_dropout=False, n_steps=1, SLATE=SLATE, full=False)
+    run_case("heads4_eval", heads4, B=3, seed=13, train_dropout=False, n_steps=1, SLATE=SLATE, full=False)
 
 
 if __name__ == "__main__":

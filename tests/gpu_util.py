@@ -39,7 +39,8 @@ def dims_from_cfg(cfg):
     return SimpleNamespace(obs_size=cfg.obs_size, obs_channels=cfg.obs_channels, vocab_size=cfg.vocab_size, d_model=cfg.d_model,
                            cnn_hidden=cfg.cnn_hidden, num_slots=cfg.num_slots, num_iterations=cfg.num_iterations,
                            slot_size=cfg.slot_size, mlp_hidden=cfg.mlp_hidden, num_dec_blocks=cfg.num_dec_blocks,
-                           num_dec_heads=cfg.num_dec_heads, dropout=cfg.dropout, use_bcdec=cfg.use_bcdec, hard=cfg.hard)
+                           num_dec_heads=cfg.num_dec_heads, dropout=cfg.dropout, use_bcdec=cfg.use_bcdec, hard=cfg.hard,
+                           num_slot_heads=int(getattr(cfg, "num_slot_heads", 1)))
 
 
 def load_params(engine, P):
@@ -100,7 +101,8 @@ def hip_relu_acts(eng, cfg, B, images=None):
     for name in ("enc1", "enc2", "enc3"):
         out.append(nchw(eng.tensor(name, (B, S, S, 64))))
     out.append(eng.tensor("sa_mlp_hidden", (B, N, 64))[sl].cpu())
-    ld = 10 * cfg.slot_size + H + 3 * 64 + 4                                  # kernels.h sa_save_layout
+    nh = int(getattr(cfg, "num_slot_heads", 1))
+    ld = 10 * cfg.slot_size + H + 3 * 64 * nh + ((nh + 3) & ~3)               # kernels.h sa_save_layout
     sv = eng.tensor("sa_save", (B, I, K, ld))[..., 10 * cfg.slot_size:10 * cfg.slot_size + H]
     for t in range(I):
         out.append(sv[sl, t].cpu())

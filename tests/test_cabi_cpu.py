@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.ocrl_abi_version() == 4
+    assert L.ocrl_abi_version() == 5
 
 
 def test_config_struct_matches_the_header():

@@ -146,13 +146,19 @@ def test_pooling_module_mirrors_reference_state_dict():
     assert [k for k in m2.state_dict() if k.startswith("mlp.")] == ["mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias", "mlp.4.weight", "mlp.4.bias"]
 
 
-def test_multi_head_slot_attention_is_refused():
-    """ocr.slotattr.num_slot_heads != 1 (ocrs/common/slot_attn.py:28,54-92) is not built on the HIP backend: constructing raises instead of
-    silently running the single-head kernels"""
+def test_multi_head_slot_attention_shapes():
+    """ocr.slotattr.num_slot_heads (ocrs/common/slot_attn.py:28,54-92) reaches the backend; shapes whose heads * slots columns do not fit one
+    16-column MFMA tile raise instead of silently running something else"""
     from ocrl_amd import ocrs
     c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2", "ocr.slotattr.num_slot_heads=2"])
-    with pytest.raises(NotImplementedError, match="num_slot_heads"):
-        ocrs.SLATE(c.ocr, c.dataset)
+    m = ocrs.SLATE(c.ocr, c.dataset)                 # 6 slots x 2 heads: supported
+    assert m._module._dims.num_slot_heads == 2
+    for over in (["ocr.slotattr.num_slot_heads=4"],                                   # 6 x 4 = 24 columns
+                 ["ocr.slotattr.num_slot_heads=2", "ocr.slotattr.num_slots=10"],      # more than 8 slots
+                 ["ocr.slotattr.num_slot_heads=5"]):                                  # 192 / 5
+        c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2"] + over)
+        with pytest.raises(NotImplementedError, match="num_slot_heads"):
+            ocrs.SLATE(c.ocr, c.dataset)
     c = compose(CFG, "train_ocr", ["ocr=slate", "dataset=random-N5C4S4S2"])
     assert c.ocr.slotattr.num_slot_heads == 1
     ocrs.SLATE(c.ocr, c.dataset)           # the shipped configuration constructs (CPU container tensors; .to(cuda) is needed to run)

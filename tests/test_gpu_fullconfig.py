@@ -158,6 +158,14 @@ def test_a64_reference_fixture_replay(golden_dir):
     replay_reference_fixture("a64 fixture", O.default_cfg(obs_size=64, num_slots=6), fx)
 
 
+@pytest.mark.parametrize("tag,over", [("heads2", dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2, num_slot_heads=2)),
+                                      ("heads4", dict(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, num_slot_heads=4))])
+def test_multi_head_reference_fixture_replay(golden_dir, tag, over):
+    """num_slot_heads = 2 / 4 (ocrs/common/slot_attn.py:54-92) — one reference update() and the next forward / backward, against the reference's numbers"""
+    fx = np.load(os.path.join(golden_dir, f"slate_{tag}_eval.npz"))
+    replay_reference_fixture(f"{tag} fixture", O.default_cfg(**over), fx)
+
+
 def test_a128_reference_fixture_replay(golden_dir):
     """config A (the headline metric's shape), B=1 — against the reference's own numbers"""
     fx = np.load(os.path.join(golden_dir, "slate_a128_eval.npz"))

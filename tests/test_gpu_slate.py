@@ -23,6 +23,10 @@ K11 = dict(obs_size=16, vocab_size=256, num_slots=11, num_iterations=2, num_dec_
 RAGGED = dict(obs_size=24, vocab_size=256, num_slots=3, num_iterations=2, num_dec_blocks=1)   # 24x24: partial conv tiles, T = 36 < one attention tile, N = 576
 V4096 = dict(obs_size=16, vocab_size=4096, num_slots=4, num_iterations=2, num_dec_blocks=1)   # real vocabulary: the 16-values-per-thread vocabulary kernels
 HARD = dict(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, hard=True)   # straight-through dVAE sample
+# several slot-attention heads (ocrs/common/slot_attn.py:54-92): 12, 16 and 15 soft-max columns
+HEADS2 = dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2, num_slot_heads=2)
+HEADS4 = dict(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, num_slot_heads=4)
+HEADS3 = dict(obs_size=32, vocab_size=256, num_slots=5, num_iterations=2, num_dec_blocks=1, num_slot_heads=3)
 
 
 def make_engine(cfg, B):
@@ -116,7 +120,8 @@ def compare_grads(tag, eng, trainer, cfg=None, P=None, obs=None, noise=None, ste
     return worst, rows
 
 
-@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2), ("hard", HARD, 2), ("ragged", RAGGED, 3), ("v4096", V4096, 2)])
+@pytest.mark.parametrize("tag,over,B", [("small", SMALL, 2), ("mid", MID, 3), ("long", LONG, 2), ("k16", K16, 2), ("k11", K11, 2), ("hard", HARD, 2), ("ragged", RAGGED, 3), ("v4096", V4096, 2),
+                                         ("heads2", HEADS2, 2), ("heads4", HEADS4, 3), ("heads3", HEADS3, 2)])
 def test_forward_backward_eval(tag, over, B):
     """dropout off: every stage of the forward, then every parameter gradient"""
     cfg = O.default_cfg(**over)

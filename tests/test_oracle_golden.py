@@ -39,6 +39,9 @@ def _replay(cfg, fx, with_masks):
 @pytest.mark.parametrize("tag,over,masks", [
     ("tiny_eval", TINY, False),
     ("tiny_train", TINY, True),
+    # multi-head slot attention (slot_attn.py:54-92) at shapes the HIP engine replays too (tests/test_gpu_slate.py)
+    ("heads2_eval", dict(obs_size=16, vocab_size=256, num_slots=6, num_iterations=3, num_dec_blocks=2, num_slot_heads=2), False),
+    ("heads4_eval", dict(obs_size=16, vocab_size=256, num_slots=4, num_iterations=2, num_dec_blocks=1, num_slot_heads=4), False),
 ])
 def test_update_matches_reference(golden_dir, tag, over, masks):
     fx = np.load(os.path.join(golden_dir, f"slate_{tag}.npz"))
