@@ -70,6 +70,11 @@ int ocrl_slate_forward(ocrl_slate* h, const float* obs, int B, float tau, int tr
 int ocrl_slate_backward(ocrl_slate* h, void* stream);
 /* SLATE_Module.forward (slate_module.py:181-196): slots [B,K,D] and attention [B,N,K] only. */
 int ocrl_slate_encode(ocrl_slate* h, const float* obs, int B, unsigned long long seed, const float* noise_slots, void* stream);
+/* Backward of the last ocrl_slate_encode for a downstream loss (poolings/base.py:53-55, learn_downstream_loss=True: the slots enter the
+ * pooling head undetached): dslots [B,K,D] -> the flat gradient buffer, overwritten: gradients of the CNN encoder, the positional
+ * embedding and the slot-attention module; zeros elsewhere.  The next ocrl_slate_clip_adam then steps those tensors only (learning rate
+ * lr[1]), as torch's Adam skips parameters without a gradient. */
+int ocrl_slate_encode_backward(ocrl_slate* h, const float* dslots, void* stream);
 /* SLATE_Module._gen_imgs (slate_module.py:163-179): greedy autoregressive token decode from the slots of the last
  * forward/encode, then dVAE decode into the "recon" tensor; metrics[4] = sum (obs - recon_tf)^2 / B.  Destroys the
  * activations of the last forward (no ocrl_slate_backward afterwards). */

@@ -104,6 +104,7 @@ int ocrl_slate_encode(ocrl_slate* h, const float* obs, int B, unsigned long long
     in.obs = obs; in.B = B; in.seed = seed; in.noise_slots = ns; in.train = 0;
     return h->m->encode(in, ST(stream));
 }
+int ocrl_slate_encode_backward(ocrl_slate* h, const float* dslots, void* stream) { GUARD(h); return h->m->encode_backward(dslots, ST(stream)); }
 int ocrl_slate_generate(ocrl_slate* h, void* stream) { GUARD(h); return h->m->generate(ST(stream)); }
 int ocrl_slate_clip_adam(ocrl_slate* h, const float lr[3], float clip, int step, float gscale, void* stream) {
     GUARD(h);

@@ -635,6 +635,7 @@ int SlateModel::forward(const StepInputs& in, hipStream_t st) {
     OCRL_REQUIRE(in.B >= 1 && in.B <= Bmax, "forward: batch %d outside [1,%d]", in.B, Bmax);
     OCRL_REQUIRE(in.obs && in.tau > 0.f, "forward: bad inputs");
     last_ = in;
+    have_enc_ = false;
     pdrop_ = in.train ? cfg.dropout : 0.f;
     RC(pack_weights(st));
     if (cfg.use_bcdec) {      // slate_module.py:218-225: loss = mse of the broadcast-decoder reconstruction
@@ -687,6 +688,7 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
     last_ = in;
     pdrop_ = 0.f;
     have_fwd_ = false;
+    have_enc_ = true;
     // measured (tools/bench_encode.py, B = 1 / 8 / 32 at 64x64): 0.457 / 0.483 / 1.006 ms replayed against 0.450 / 0.473 / 0.988 ms eager -- the
     // call is bound by its chain of ~30 dependent small kernels on the GPU, not by the host's launches, so the replay is opt-in
     if (enc_graph_mode_ < 0) { const char* e = getenv("OCRL_ENCODE_GRAPH"); enc_graph_mode_ = e ? atoi(e) : 0; }
@@ -728,9 +730,25 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
 // the rows of earlier positions independent of later tokens, so here every step pushes ONE new row per image through the blocks and
 // attends to the keys / values of the earlier rows kept in the fused q|k|v buffer of each block (KV cache): T steps of B rows instead
 // of T passes of up to B*T rows.  Clobbers the decoder activations: no backward() afterwards.  metrics[4] = mse of the generated image.
+// Fine-tuning the encoder through a downstream loss (poolings/base.py:53-55, learn_downstream_loss: the slots reach the pooling head
+// undetached): d loss / d slots of the last encode() -> gradients of the CNN encoder, the positional embedding and the slot-attention
+// module.  Every other tensor of the flat gradient buffer is zero and is skipped by the next clip_adam(), as torch's Adam skips
+// parameters whose .grad is None.
+int SlateModel::encode_backward(const float* dslots, hipStream_t st) {
+    OCRL_REQUIRE(have_enc_, "encode_backward: call encode first (its activations are what is differentiated)");
+    OCRL_REQUIRE(g_ && dslots, "encode_backward: no gradient buffer bound / null dslots");
+    RC(fill_launch(g_, flat_size_, 0.f, st));
+    RC(copy_launch(dslots, gslots_, (long long)last_.B * K * D, st));
+    RC(bwd_encoder(st));
+    have_enc_ = false;
+    enc_only_grads_ = true;
+    return 0;
+}
+
 int SlateModel::generate(hipStream_t st) {
     OCRL_REQUIRE(!cfg.use_bcdec, "generate: the autoregressive decoder is not part of the use_bcdec configuration");
     OCRL_REQUIRE(last_.B > 0 && last_.obs, "generate: run forward or encode first");
+    have_enc_ = false;
     const int B = last_.B;
     const long long BK = (long long)B * K;
     pdrop_ = 0.f;
@@ -1120,6 +1138,7 @@ int SlateModel::bwd_dvae(hipStream_t st) {
 int SlateModel::backward(hipStream_t st) {
     OCRL_REQUIRE(have_fwd_, "backward: call forward first");
     OCRL_REQUIRE(g_, "backward: no gradient buffer bound");
+    enc_only_grads_ = false;
     if (cfg.use_bcdec) {
         RC(fill_launch(g_, flat_size_, 0.f, st));       // dVAE / transformer / slotproj parameters get no gradient in this mode
         RC(bwd_bcdec(st));
@@ -1179,6 +1198,13 @@ int SlateModel::grad_norm(hipStream_t st) {
 int SlateModel::clip_adam(const float lr[3], float clip, int step, float gscale, hipStream_t st) {
     OCRL_REQUIRE(m_ && v_, "clip_adam: optimiser state not bound");
     RC(grad_norm(st));
+    if (enc_only_grads_) {       // after encode_backward(): the encoder tensors only (group 1 up to the slot projection / broadcast decoder)
+        long long end = group_begin_[2];
+        for (const ParamInfo& q : params_)
+            if (q.group == 1 && (q.name.rfind("_slotproj.", 0) == 0 || q.name.rfind("_dec.", 0) == 0) && q.offset < end) end = q.offset;
+        const long long b0 = group_begin_[1];
+        return clip_adam_launch(p_ + b0, g_ + b0, m_ + b0, v_ + b0, end - b0, metrics_ + 3, clip, lr[1], 0.9f, 0.999f, 1e-8f, step, gscale, st);
+    }
     for (int g = 0; g < 3; ++g) {
         if (cfg.use_bcdec && g != 1) continue;      // parameters without gradients are skipped, as torch's Adam does
         const long long b0 = group_begin_[g], n = group_begin_[g + 1] - b0;

@@ -124,7 +124,13 @@ class SlateEngine:
     def encode(self, obs, seed, slot_noise=None):
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous()
         self._keep = (obs, slot_noise)
+        self.encode_generation = getattr(self, "encode_generation", 0) + 1      # which encode() the saved activations belong to
         _lib.check(self.L.ocrl_slate_encode(self.h, _lib.ptr(obs), obs.shape[0], int(seed), _lib.ptr(slot_noise), self.stream))
+
+    def encode_backward(self, dslots):
+        """d loss / d slots of the last encode() -> flat_g (encoder tensors; zeros elsewhere)"""
+        assert dslots.is_cuda and dslots.dtype == torch.float32 and dslots.is_contiguous()
+        _lib.check(self.L.ocrl_slate_encode_backward(self.h, _lib.ptr(dslots), self.stream))
 
     def clip_adam(self, lrs, clip, grad_scale=1.0):
         self.adam_step += 1

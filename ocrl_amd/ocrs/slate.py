@@ -141,6 +141,7 @@ class SLATE_Module(nn.Module):
         self._seed = 0
         self._step_seed = 0
         self._injected_noise = None
+        self.finetune_through_slots = False      # set by poolings.Base when learn_downstream_loss=True: forward() returns attached slots
 
     # ---- container plumbing
     def _query_spec(self, _lib):
@@ -248,6 +249,13 @@ class SLATE_Module(nn.Module):
         self._ensure_engine(obs.shape[0])
         return obs.contiguous().float()
 
+    def _grad_hook(self):
+        """a one-element leaf that requires grad: gives _EncodeGrad a differentiable input, so autograd calls its backward"""
+        h = getattr(self, "_grad_hook_t", None)
+        if h is None or h.device != self._device:
+            h = self._grad_hook_t = torch.zeros(1, device=self._device, requires_grad=True)
+        return h
+
     # ---- reference surface
     def update_tau(self, step: int) -> None:
         self._tau = cosine_anneal(step, self._tau_start, self._tau_final, 0, self._tau_steps)
@@ -286,6 +294,9 @@ class SLATE_Module(nn.Module):
             feats = self.engine.tensor("feats", (B, self._obs_size ** 2, self._dims.cnn_hidden))
             return torch.cat([feats, obs.permute(0, 2, 3, 1).reshape(B, -1, obs.shape[1])], dim=-1)
         slots = self.engine.tensor("slots", (B, self._num_slots, self._dims.slot_size)).clone()
+        if getattr(self, "finetune_through_slots", False) and torch.is_grad_enabled():
+            # poolings/base.py:53-55 (learn_downstream_loss): the slots stay attached, so a downstream loss reaches the encoder
+            slots = _EncodeGrad.apply(self._grad_hook(), slots, self, self.engine.encode_generation)
         if with_attns or with_masks:
             attns = self._attns_image(B).clone()
             if with_attns:
@@ -358,6 +369,24 @@ class SLATE_Module(nn.Module):
         sd = {k: v for k, v in state_dict.items()}
         out = super().load_state_dict(sd, strict=strict)
         return out
+
+
+class _EncodeGrad(torch.autograd.Function):
+    """Keeps the slots of SLATE_Module.forward attached for a downstream loss: backward hands d loss / d slots to
+    ocrl_slate_encode_backward, which fills the flat gradient buffer (encoder tensors) from the activations the encode() call saved."""
+
+    @staticmethod
+    def forward(ctx, hook, slots, module, generation):
+        ctx.module, ctx.generation = module, generation
+        return slots.view_as(slots)
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.module.engine
+        if eng.encode_generation != ctx.generation:
+            raise RuntimeError("ocrl_amd: the encoder ran again before backward(); only the most recent model(obs) call can be differentiated")
+        eng.encode_backward(g.contiguous())
+        return torch.zeros(1, device=g.device), None, None, None
 
 
 class FusedAdam:

@@ -9,6 +9,14 @@ class Base:
         self._config = config
         self._learn_aux_loss = config.learn_aux_loss
         self._learn_downstream_loss = config.learn_downstream_loss
+        if self._learn_downstream_loss:
+            # poolings/base.py:53-55: the slots reach the pooling head undetached.  The encoder's forward is a library call, not a torch
+            # graph: its module keeps the slots attached through an autograd function that routes d loss / d slots into
+            # ocrl_slate_encode_backward (ocrs/slate.py::_EncodeGrad); set_zero_grad() / do_step() then act on the flat buffers
+            mod = getattr(ocr, "_module", None)
+            if mod is None or not hasattr(mod, "finetune_through_slots") or getattr(mod, "_use_cnn_feat", False):
+                raise NotImplementedError("learn_downstream_loss=True is built for the SLATE / Slot-Attention encoder's slots (not use_cnn_feat, not IODINE)")
+            mod.finetune_through_slots = True
         self._load_ocr()
         self.rep_dim = self._module.rep_dim
         if hasattr(self._config, "learning") and hasattr(self._config.learning, "lr"):
@@ -40,11 +48,9 @@ class Base:
         else:
             state = self._ocr(obs)
             metrics = {}
-        # the slots are detached unless the encoder is fine-tuned through the downstream loss (poolings/base.py:53); this backend's
-        # encoder forward is not differentiable through torch autograd, so fine-tuning is refused rather than silently dropped
-        if self._learn_downstream_loss:
-            raise NotImplementedError("learn_downstream_loss=True (end-to-end fine-tuning of the encoder through the pooling) is not supported")
-        state = self._module(state.detach())
+        # detach if not fine-tuning (poolings/base.py:53-55)
+        state = state.detach() if not self._learn_downstream_loss else state
+        state = self._module(state)
         return (state, metrics) if with_loss else state
 
     def train(self) -> None:

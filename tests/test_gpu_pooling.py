@@ -259,3 +259,69 @@ def test_gt_state_embeddings_match_reference_fixture(mode):
         worst = max(worst, np.abs(got - ref[3:]).max() / max(np.abs(ref[3:]).max(), 1e-3 * gmax))
     log(f"[pooling {mode}_embedding] output {e_out:.2e}; embedding-parameter gradients worst {worst:.2e}")
     assert e_out < 2e-5 and worst < 3e-4
+
+
+def test_learn_downstream_loss_reaches_the_encoder():
+    """pooling.learn_downstream_loss=True (poolings/base.py:53-55): the slots enter the pooling head undetached, so loss.backward() must
+    leave d loss / d theta on the encoder (CNN, positional embedding, slot attention), set_zero_grad() / do_step() (poolings/base.py:36-44,
+    utils/property_predictor.py:204-211) must step exactly those tensors.  Checked against autograd through the two oracles chained."""
+    from oracle import slate_oracle as O
+    from ocrl_amd import ocrs, poolings
+    from ocrl_amd.utils.config import compose
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ocr_cfg = compose(os.path.join(root, "configs"), "train_ocr", ["ocr=slate", "ocr.slotattr.num_slots=5", "ocr.dvae.vocab_size=256",
+                                                                     "ocr.tfdec.num_dec_blocks=1", "dataset=random-N5C4S4S2", "dataset.obs_size=32"])
+    torch.manual_seed(11)
+    ocr = ocrs.SLATE(ocr_cfg.ocr, ocr_cfg.dataset)
+    ocr.to("cuda:0")
+    pool = poolings.Transformer(ocr, _pool_cfg(learn_downstream_loss=True))
+    pool.to("cuda:0")
+    pool.eval()                       # no dropout in the pooling head; the encoder has none on this path
+    B, K, D = 3, 5, ocr.rep_dim
+    g = torch.Generator().manual_seed(12)
+    obs = torch.rand(B, 3, 32, 32, generator=g)
+    slot_noise = torch.randn(B, K, D, generator=g)
+    cot = torch.randn(B, 128, generator=g)
+    before = {k: t.detach().cpu().clone() for k, t in ocr._module.state_dict().items()}
+    # ---- HIP: forward through encoder + pooling, backward through both
+    pool.set_zero_grad()
+    ocr._module.inject_noise(dict(slots=slot_noise.cuda()))
+    v = pool(obs.cuda())
+    assert v.requires_grad
+    (v * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    eng = ocr._module.engine
+    got = {p.name: eng.view(eng.flat_g, p).cpu().clone() for p in eng.params}
+    # ---- oracle: the same chain on the CPU with autograd
+    cfg = O.default_cfg(obs_size=32, num_slots=5, vocab_size=256, num_dec_blocks=1)
+    P = {k: t.clone().requires_grad_(t.dtype.is_floating_point) for k, t in before.items()}
+    Pp = {k: t.detach().cpu().clone().requires_grad_(True) for k, t in pool._module.state_dict().items()}
+    slots_ref, _ = O.slot_encoder(P, O.cnn_encode(P, obs), slot_noise, cfg)
+    v_ref = PO.forward(Pp, slots_ref, PO.default_cfg(num_slots=5, rep_dim=D))
+    assert relerr(v, v_ref) < 2e-5
+    (v_ref * cot).sum().backward()
+    enc = [n for n in got if n.startswith(("_enc.", "_enc_pos.", "_slotattn."))]
+    gmax = max(float(P[n].grad.abs().max()) for n in enc)
+    errs = {n: relerr(got[n], P[n].grad, floor=1e-4 * gmax) for n in enc}
+    worst = max(errs, key=errs.get)
+    rest = [n for n in got if n not in enc]
+    log(f"[learn_downstream_loss] pooled vector {relerr(v, v_ref):.2e}; encoder gradients through the pooling head: worst {worst}={errs[worst]:.2e} over {len(enc)} tensors; "
+        f"{len(rest)} other tensors zero")
+    assert errs[worst] < 2e-4, errs
+    for n in rest:                     # dVAE, slot projection, transformer decoder: no gradient on this path
+        assert P[n].grad is None and not got[n].any(), n
+    # pooling-side gradients arrive through torch autograd as before
+    for n, p_ in pool._module.named_parameters():
+        assert relerr(p_.grad, Pp[n].grad, floor=1e-4 * float(Pp[n].grad.abs().max() + 1e-12)) < 3e-4, n
+    # ---- do_step(): Adam on the tensors that have a gradient, nothing else moves (torch's Adam skips parameters whose .grad is None)
+    pool.do_step()
+    torch.cuda.synchronize()
+    after = {k: t.detach().cpu() for k, t in ocr._module.state_dict().items()}
+    lr = float(ocr_cfg.ocr.learning.lr_enc)
+    for n in enc:
+        gr = P[n].grad
+        want = before[n] - lr * gr / (gr.abs() + 1e-8)           # first Adam step: m_hat = g, v_hat = g^2
+        big = gr.abs() > 1e-3 * gmax                               # elements whose gradient sign is not rounding noise
+        assert (after[n] - want)[big].abs().max() <= 1e-3 * lr, n
+    for n in rest:
+        assert torch.equal(after[n], before[n]), n
