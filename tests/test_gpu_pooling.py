@@ -322,6 +322,8 @@ def test_learn_downstream_loss_reaches_the_encoder():
         gr = P[n].grad
         want = before[n] - lr * gr / (gr.abs() + 1e-8)           # first Adam step: m_hat = g, v_hat = g^2
         big = gr.abs() > 1e-3 * gmax                               # elements whose gradient sign is not rounding noise
-        assert (after[n] - want)[big].abs().max() <= 1e-3 * lr, n
+        if big.any():               # norm_slots.bias: the exact gradient is zero
+            assert (after[n] - want)[big].abs().max() <= 1e-3 * lr, n
+        assert (after[n] - before[n]).abs().max() <= 1.001 * lr, n      # an Adam step never exceeds lr per element
     for n in rest:
         assert torch.equal(after[n], before[n]), n
