@@ -75,6 +75,10 @@ int ocrl_slate_encode(ocrl_slate* h, const float* obs, int B, unsigned long long
  * embedding and the slot-attention module; zeros elsewhere.  The next ocrl_slate_clip_adam then steps those tensors only (learning rate
  * lr[1]), as torch's Adam skips parameters without a gradient. */
 int ocrl_slate_encode_backward(ocrl_slate* h, const float* dslots, void* stream);
+/* Serving with a frozen encoder (sb3s/ocr_extractor.py:33-36 with a pre-trained checkpoint and finetuning off): on != 0 promises that
+ * the parameters do not change until the next call with on = 0 (or a clip_adam / bind), so ocrl_slate_encode builds the derived
+ * weight images once instead of at every call.  Writing the flat parameter buffer while frozen leaves them stale. */
+int ocrl_slate_freeze_weights(ocrl_slate* h, int on);
 /* SLATE_Module._gen_imgs (slate_module.py:163-179): greedy autoregressive token decode from the slots of the last
  * forward/encode, then dVAE decode into the "recon" tensor; metrics[4] = sum (obs - recon_tf)^2 / B.  Destroys the
  * activations of the last forward (no ocrl_slate_backward afterwards). */

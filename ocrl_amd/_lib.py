@@ -56,6 +56,7 @@ def lib():
     L.ocrl_slate_generate.argtypes = [p, p]
     L.ocrl_slate_encode.argtypes = [p, p, c_int, c_ulonglong, p, p]
     L.ocrl_slate_encode_backward.argtypes = [p, p, p]
+    L.ocrl_slate_freeze_weights.argtypes = [p, c_int]
     L.ocrl_slate_clip_adam.argtypes = [p, POINTER(c_float * 3), c_float, c_int, c_float, p]
     L.ocrl_slate_grad_norm.argtypes = [p, p]
     L.ocrl_slate_metrics.argtypes = [p]

@@ -105,6 +105,7 @@ int ocrl_slate_encode(ocrl_slate* h, const float* obs, int B, unsigned long long
     return h->m->encode(in, ST(stream));
 }
 int ocrl_slate_encode_backward(ocrl_slate* h, const float* dslots, void* stream) { GUARD(h); return h->m->encode_backward(dslots, ST(stream)); }
+int ocrl_slate_freeze_weights(ocrl_slate* h, int on) { GUARD(h); h->m->freeze_weights(on != 0); return 0; }
 int ocrl_slate_generate(ocrl_slate* h, void* stream) { GUARD(h); return h->m->generate(ST(stream)); }
 int ocrl_slate_clip_adam(ocrl_slate* h, const float lr[3], float clip, int step, float gscale, void* stream) {
     GUARD(h);

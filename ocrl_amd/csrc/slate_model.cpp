@@ -271,8 +271,8 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     p_ = p; g_ = g; m_ = m; v_ = v;
     ws_ = static_cast<char*>(ws);
     named_.clear();
-    for (auto& kv : enc_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);      // captured against the old buffers
-    enc_graphs_.clear();
+    clear_encode_graphs();       // captured against the old buffers
+    packs_valid_ = false;
     layout_workspace(true);
     if (!side_) {
         // OCRL_OVERLAP (default 5): the dVAE branch (many short 64-wide products that do not fill the machine) runs on a side stream.
@@ -693,14 +693,19 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
     // call is bound by its chain of ~30 dependent small kernels on the GPU, not by the host's launches, so the replay is opt-in
     if (enc_graph_mode_ < 0) { const char* e = getenv("OCRL_ENCODE_GRAPH"); enc_graph_mode_ = e ? atoi(e) : 0; }
     const bool graph = enc_graph_mode_ && in.B <= 32 && !in.noise_slots && obs_stage_;
+    // frozen weights (ocrl_slate_freeze_weights: serving with a pre-trained encoder): the derived weight images -- convolution packs,
+    // slot-attention block, position map; 8 launches, ~45 us of a 0.47 ms call at B = 1 -- are built once
+    const bool need_pack = !(frozen_ && packs_valid_);
     if (!graph) {
-        RC(pack_weights(st, true));
+        if (need_pack) RC(pack_weights(st, true));
+        packs_valid_ = frozen_;
         return fwd_encoder(in, st);
     }
     EncGraph& eg = enc_graphs_[in.B];
-    if (!eg.warm) {            // first call at this batch size runs eagerly: one-time kernel attributes are set outside the capture
+    if (!eg.warm || need_pack) {            // first call at this batch size runs eagerly: one-time kernel attributes are set outside the capture
         eg.warm = 1;
-        RC(pack_weights(st, true));
+        if (need_pack) RC(pack_weights(st, true));
+        packs_valid_ = frozen_;
         return fwd_encoder(in, st);
     }
     const size_t bytes = (size_t)in.B * cfg.obs_channels * N * sizeof(float);
@@ -713,7 +718,7 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
         // captured on a stream of its own (the caller's may be the legacy default stream, which cannot capture); replayed on the caller's
         if (!cap_) OCRL_HIP(hipStreamCreateWithFlags(&cap_, hipStreamNonBlocking));
         OCRL_HIP(hipStreamBeginCapture(cap_, hipStreamCaptureModeThreadLocal));
-        int rc = pack_weights(cap_, true);
+        int rc = frozen_ ? 0 : pack_weights(cap_, true);
         if (!rc) rc = fwd_encoder(gi, cap_);
         const hipError_t ce = hipStreamEndCapture(cap_, &g);
         if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -734,6 +739,11 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
 // undetached): d loss / d slots of the last encode() -> gradients of the CNN encoder, the positional embedding and the slot-attention
 // module.  Every other tensor of the flat gradient buffer is zero and is skipped by the next clip_adam(), as torch's Adam skips
 // parameters whose .grad is None.
+void SlateModel::clear_encode_graphs() {
+    for (auto& kv : enc_graphs_) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    enc_graphs_.clear();
+}
+
 int SlateModel::encode_backward(const float* dslots, hipStream_t st) {
     OCRL_REQUIRE(have_enc_, "encode_backward: call encode first (its activations are what is differentiated)");
     OCRL_REQUIRE(g_ && dslots, "encode_backward: no gradient buffer bound / null dslots");
@@ -1197,6 +1207,7 @@ int SlateModel::grad_norm(hipStream_t st) {
 
 int SlateModel::clip_adam(const float lr[3], float clip, int step, float gscale, hipStream_t st) {
     OCRL_REQUIRE(m_ && v_, "clip_adam: optimiser state not bound");
+    packs_valid_ = false;
     RC(grad_norm(st));
     if (enc_only_grads_) {       // after encode_backward(): the encoder tensors only (group 1 up to the slot projection / broadcast decoder)
         long long end = group_begin_[2];

@@ -58,6 +58,8 @@ public:
     int forward(const StepInputs& in, hipStream_t st);          // loss terms -> metrics()
     int backward(hipStream_t st);                               // fills the flat gradient buffer
     int encode(const StepInputs& in, hipStream_t st);           // slots + attention only (inference path)
+    void freeze_weights(bool on) { frozen_ = on; packs_valid_ = false; clear_encode_graphs(); }
+    void clear_encode_graphs();
     int encode_backward(const float* dslots, hipStream_t st);   // gradient of the last encode() wrt the encoder's parameters (downstream fine-tuning)
     int generate(hipStream_t st);                               // greedy autoregressive image from the last step's slots
     int clip_adam(const float lr[3], float clip, int step, float gscale, hipStream_t st);
@@ -117,6 +119,7 @@ private:
     StepInputs last_;
     float pdrop_ = 0.f;
     bool have_fwd_ = false;
+    bool frozen_ = false, packs_valid_ = false;   // freeze_weights(): encode() re-uses the derived weight images (serving: the parameters do not change)
     bool have_enc_ = false;         // the last call was encode(): its activations are what encode_backward() differentiates
     bool enc_only_grads_ = false;   // the gradient buffer holds an encode_backward(): only the encoder tensors have gradients
     bool have_scores_ = false;        // zraw_ holds the Gumbel scores of last_ (not yet overwritten by their gradient)

@@ -127,6 +127,10 @@ class SlateEngine:
         self.encode_generation = getattr(self, "encode_generation", 0) + 1      # which encode() the saved activations belong to
         _lib.check(self.L.ocrl_slate_encode(self.h, _lib.ptr(obs), obs.shape[0], int(seed), _lib.ptr(slot_noise), self.stream))
 
+    def freeze_weights(self, on=True):
+        """the parameters will not change: encode() keeps its derived weight images between calls"""
+        _lib.check(self.L.ocrl_slate_freeze_weights(self.h, int(bool(on))))
+
     def encode_backward(self, dslots):
         """d loss / d slots of the last encode() -> flat_g (encoder tensors; zeros elsewhere)"""
         assert dslots.is_cuda and dslots.dtype == torch.float32 and dslots.is_contiguous()

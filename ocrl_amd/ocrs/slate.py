@@ -236,6 +236,8 @@ class SLATE_Module(nn.Module):
             b.data = b.data.to(eng.device)
         self.engine = eng
         self._max_batch = batch
+        if getattr(self, "_frozen", False):
+            eng.freeze_weights(True)
         pending, self._pending_opt = getattr(self, "_pending_opt", None), None
         if pending is not None:       # optimiser state loaded before .to(device), as the reference's callers do (sb3s/ocr_extractor.py:33-36)
             pending[0].load_state_dict(pending[1])
@@ -248,6 +250,28 @@ class SLATE_Module(nn.Module):
             raise RuntimeError("ocrl_amd: observations must live on the GPU (to_device(batch, device))")
         self._ensure_engine(obs.shape[0])
         return obs.contiguous().float()
+
+    def freeze_weights(self, on=True):
+        """Serving with a frozen, pre-trained encoder (sb3s/ocr_extractor.py:33-36 without finetuning): promise that the parameters do not
+        change, so model(obs) stops rebuilding the derived weight images at every call.  Call after the checkpoint is loaded."""
+        self._frozen = bool(on)
+        if self.engine is not None:
+            self.engine.freeze_weights(self._frozen)
+
+    def _publish_encoder_grads(self):
+        """after ocrl_slate_encode_backward: the parameters' .grad are views of the flat gradient buffer (set in _ensure_engine); an
+        optimiser's zero_grad(set_to_none=True) drops them, so the tensors that just received a gradient get their view back.  The
+        others stay None and a torch optimiser skips them, as it does for the reference's unused parameters."""
+        eng = self.engine
+        named = dict(self.named_parameters())
+        for p in eng.params:
+            if p.name.startswith(("_enc.", "_enc_pos.", "_slotattn.")):
+                t = named[p.name]
+                view = eng.view(eng.flat_g, p)
+                if t.grad is None:
+                    t.grad = view
+                elif t.grad.data_ptr() != view.data_ptr():
+                    t.grad.add_(view)
 
     def _grad_hook(self):
         """a one-element leaf that requires grad: gives _EncodeGrad a differentiable input, so autograd calls its backward"""
@@ -368,6 +392,8 @@ class SLATE_Module(nn.Module):
     def load_state_dict(self, state_dict, strict=True):
         sd = {k: v for k, v in state_dict.items()}
         out = super().load_state_dict(sd, strict=strict)
+        if self.engine is not None and getattr(self, "_frozen", False):
+            self.engine.freeze_weights(True)        # new weights: the derived images are rebuilt once at the next call
         return out
 
 
@@ -386,6 +412,7 @@ class _EncodeGrad(torch.autograd.Function):
         if eng.encode_generation != ctx.generation:
             raise RuntimeError("ocrl_amd: the encoder ran again before backward(); only the most recent model(obs) call can be differentiated")
         eng.encode_backward(g.contiguous())
+        ctx.module._publish_encoder_grads()
         return torch.zeros(1, device=g.device), None, None, None
 
 

@@ -327,3 +327,75 @@ def test_learn_downstream_loss_reaches_the_encoder():
         assert (after[n] - before[n]).abs().max() <= 1.001 * lr, n      # an Adam step never exceeds lr per element
     for n in rest:
         assert torch.equal(after[n], before[n]), n
+
+
+def test_extractor_trains_or_freezes_the_encoder_as_get_ocr_does(tmp_path):
+    """utils/tools.py:323-347 (get_ocr) decides what sb3s/ocr_extractor.py:33-45 owns: the encoder *module* (no checkpoint, or
+    ocr_checkpoint.finetuning) -- its parameters belong to the policy and the RL loss trains them through the slots -- or the wrapper
+    object of a pre-trained encoder, which no optimiser sees.  Trainable: a torch optimiser over extractor.parameters() (with its default
+    zero_grad(set_to_none=True)) must find gradients on the encoder tensors and only there.  Frozen: the encoder's derived weight images
+    are built once (ocrl_slate_freeze_weights) and rebuilt when new weights are loaded."""
+    from ocrl_amd import ocrs
+    from ocrl_amd.sb3s import OCRExtractor
+    from ocrl_amd.utils.config import compose
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ocr_cfg = compose(os.path.join(root, "configs"), "train_ocr", ["ocr=slate", "ocr.slotattr.num_slots=5", "ocr.dvae.vocab_size=256",
+                                                                     "ocr.tfdec.num_dec_blocks=1", "dataset=random-N5C4S4S2", "dataset.obs_size=32"])
+    obs = torch.rand(4, 3, 32, 32, device="cuda")
+    noise = torch.randn(4, 5, 192, device="cuda")
+    # ---- trainable: no checkpoint
+    full = types.SimpleNamespace(ocr=ocr_cfg.ocr, env=ocr_cfg.dataset, pooling=_pool_cfg(), num_envs=4, device="cuda:0")
+    torch.manual_seed(21)
+    ex = OCRExtractor(None, full).to("cuda:0")
+    ex.train()
+    names = [n for n, _ in ex.named_parameters()]
+    assert any(n.startswith("_ocr._enc.") for n in names) and any(n.startswith("_pooling.") for n in names)
+    opt = torch.optim.Adam([p for p in ex.parameters() if p.dtype.is_floating_point], lr=1e-3)
+    eng = ex._ocr.engine
+    for it in range(2):
+        opt.zero_grad()                                # set_to_none=True: every .grad view of the flat buffer is dropped
+        before = {n: p.detach().clone() for n, p in ex.named_parameters()}
+        ex._ocr.inject_noise(dict(slots=noise))
+        f = ex(obs)
+        assert f.requires_grad
+        f.square().sum().backward()
+        with_grad = {n for n, p in ex.named_parameters() if p.grad is not None}
+        enc = {n for n in names if n.startswith(("_ocr._enc.", "_ocr._enc_pos.", "_ocr._slotattn."))}
+        assert with_grad == enc | {n for n in names if n.startswith("_pooling.")}, sorted(with_grad ^ (enc | {n for n in names if n.startswith("_pooling.")}))[:5]
+        for p in eng.params:                           # the published gradients are the flat buffer's
+            t = dict(ex._ocr.named_parameters())[p.name]
+            if t.grad is not None:
+                assert torch.equal(t.grad, eng.view(eng.flat_g, p)) and torch.isfinite(t.grad).all()
+        opt.step()
+        moved = {n for n, p in ex.named_parameters() if not torch.equal(p.detach(), before[n])}
+        assert "_ocr._enc._encoder.0.m.weight" in moved and "_ocr._slotattn.slot_attention.gru.weight_hh" in moved
+        assert not any(n.startswith(("_ocr._dvae.", "_ocr._tfdec.", "_ocr._slotproj.", "_ocr._dict.")) for n in moved)
+    # the optimiser wrote through the parameter views into the flat buffer the kernels read
+    assert torch.equal(dict(ex._ocr.named_parameters())["_enc._encoder.0.m.weight"].detach().flatten(),
+                       eng.view(eng.flat_p, next(p for p in eng.params if p.name == "_enc._encoder.0.m.weight")).flatten())
+    # ---- frozen: pre-trained checkpoint, no finetuning
+    src = ocrs.SLATE(ocr_cfg.ocr, ocr_cfg.dataset); src.to("cuda:0")
+    path = str(tmp_path / "model_latest.pth")
+    torch.save(src.save(), path)
+    pc = _pool_cfg(ocr_checkpoint=types.SimpleNamespace(run_id="", local_file=path, finetuning=False))
+    fx = OCRExtractor(None, types.SimpleNamespace(ocr=ocr_cfg.ocr, env=ocr_cfg.dataset, pooling=pc, num_envs=4, device="cuda:0")).to("cuda:0")
+    fx.eval()
+    assert not any(n.startswith("_ocr.") for n, _ in fx.named_parameters())          # the wrapper is not a module: nothing to train
+    outs = []
+    for _ in range(3):                                 # call 1 builds the weight images, calls 2 and 3 re-use them
+        fx._ocr._module.inject_noise(dict(slots=noise))
+        outs.append(fx(obs))
+    assert not outs[0].requires_grad and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    src._module.inject_noise(dict(slots=noise))
+    want = fx._pooling(src(obs))                       # the unfrozen wrapper with the same weights
+    assert torch.equal(outs[0], want)
+    # new weights loaded while frozen: picked up at the next call
+    sd = {k: (v * 1.5 if k == "_enc._encoder.3.weight" else v) for k, v in src._module.state_dict().items()}
+    fx._ocr._module.load_state_dict(sd)
+    fx._ocr._module.inject_noise(dict(slots=noise))
+    assert not torch.equal(fx(obs), outs[0])
+    # finetuning a pre-trained encoder: the module again
+    pc2 = _pool_cfg(ocr_checkpoint=types.SimpleNamespace(run_id="", local_file=path, finetuning=True))
+    tx = OCRExtractor(None, types.SimpleNamespace(ocr=ocr_cfg.ocr, env=ocr_cfg.dataset, pooling=pc2, num_envs=4, device="cuda:0")).to("cuda:0")
+    assert any(n.startswith("_ocr._enc.") for n, _ in tx.named_parameters())
+    assert torch.equal(tx._ocr.engine.flat_p, src._module.engine.flat_p)
