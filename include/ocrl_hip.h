@@ -116,6 +116,11 @@ int ocrl_gemm(const float* A, const float* B, float* C, int M, int N, int K, int
  * zero) with the reference-layout weight w [64,cin,ks,ks]; y [B,H,W,64] NHWC.  ws: ks*ks*cin_pad*64 floats. */
 int ocrl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int cin, int cin_pad, int ks,
                     int relu, float* ws, void* stream);
+/* The same convolution for a few images at a time (the RL extractor's encode(): sb3s/ocr_extractor.py:45 at num_envs images): 5x5 /
+ * 64-channel layers whose grid would leave most of the GPU idle run a kernel that splits one output tile over four waves and two
+ * workgroups (k-split, ordered sum).  Same arguments and result up to fp32 summation order; other shapes take the kernel above. */
+int ocrl_conv2d_fwd_lowlat(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int cin, int cin_pad, int ks,
+                           int relu, float* ws, void* stream);
 /* grad wrt input of the same conv (square 64->64 layers): dx = conv_transpose(dy, w) * (mask > 0 if mask). ws: 2*ks*ks*64*64 floats. */
 int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream);
 /* grad wrt weight (reference layout [64,cin,ks,ks]) and bias [64] (may be NULL); ws from ocrl_conv2d_wgrad_ws_floats. */

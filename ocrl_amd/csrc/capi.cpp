@@ -141,6 +141,13 @@ int ocrl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
     a.X = x; a.Wp = ws; a.Y = y; a.B = B; a.H = H; a.W = W; a.bias = bias; a.relu = relu;
     return conv_fwd_launch(a, ks, cin_pad, 64, ST(stream));
 }
+int ocrl_conv2d_fwd_lowlat(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int cin, int cin_pad, int ks, int relu,
+                           float* ws, void* stream) {
+    if (conv_pack_launch(w, ws, nullptr, ks, cin_pad, 64, cin, ST(stream))) return 1;
+    ConvArgs a;
+    a.X = x; a.Wp = ws; a.Y = y; a.B = B; a.H = H; a.W = W; a.bias = bias; a.relu = relu;
+    return conv_fwd_launch(a, ks, cin_pad, 64, ST(stream), 1);
+}
 int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream) {
     float* bw = ws + (size_t)ks * ks * 64 * 64;
     if (conv_pack_launch(w, ws, bw, ks, 64, 64, 64, ST(stream))) return 1;

@@ -218,6 +218,90 @@ __global__ __launch_bounds__(256, (ConvCfg<KS, CIN>::WGS)) void conv_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Low-latency forward for grids that do not fill the machine (the RL extractor's encode() at num_envs images: one 64x64 image is 32
+// tiles of the kernel above, each a 43 us dependent MFMA chain on one CU while 224 CUs idle).  One workgroup = one row segment of 32
+// pixels x 32 output channels; its four waves split the INPUT channels (16 each: k-split) over all KS*KS taps, each wave stages only
+// its own channels of the halo in a wave-private LDS region (no workgroup barrier before the MFMAs), and the four partial 32x32 tiles
+// are summed in a fixed order in the epilogue.  200 MFMAs per wave instead of 1600: ~8 us per layer at 256 workgroups.
+// Forward features only (bias, ReLU, position map).
+template <int KS, int CIN>
+__global__ __launch_bounds__(256) void conv_lat_kernel(ConvArgs p) {
+    static_assert(CIN == 64, "four waves x 16 input channels");
+    constexpr int P = KS / 2, HW_ = TW + KS - 1, NPX = KS * HW_;
+    constexpr int LDW = 20;                       // 16 channels + 4: conflict-free ds_read_b128 across 16 pixels
+    constexpr int REGION = NPX * LDW;             // floats per wave (>= the 32 x 36 partial patch)
+    static_assert(REGION >= 32 * 36, "partial patch must fit the wave's halo region");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int y = bid % p.H;
+    const int b = bid / p.H;
+    const int x0 = tx * TW, half = blockIdx.y;
+    float* reg = smem + wave * REGION;
+    {   // this wave's 16 channels of the KS x (32 + KS - 1) halo: every load issued before the first LDS store
+        constexpr int TOTAL = NPX * 4, NLD = (TOTAL + 63) / 64;
+        const float* Xb = p.X + (size_t)b * p.H * p.W * CIN + wave * 16;
+        float4 hv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = lane + i * 64, c4 = idx & 3, hp = idx >> 2;
+            const int hx = hp % HW_, hy = hp / HW_;
+            const int yy = y - P + hy, xx = x0 - P + hx;
+            hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TOTAL && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)yy * p.W + xx) * CIN + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = lane + i * 64;
+            if (idx < TOTAL) *reinterpret_cast<float4*>(reg + (idx >> 2) * LDW + (idx & 3) * 4) = hv[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // packed weights [tap][CIN/8][64][8]: this wave's chunks 2w, 2w+1; this half's output channels
+    const float* wl = p.Wp + ((size_t)(2 * wave) * 64 + half * 32 + li) * 8 + 4 * lh;
+    constexpr int NIT = KS * KS * 2, RING = 10;
+    float4 rb[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) rb[i] = *reinterpret_cast<const float4*>(wl + ((size_t)(i >> 1) * (CIN / 8) + (i & 1)) * 64 * 8);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int tap = it >> 1, cc = it & 1, ky = tap / KS, kx = tap - ky * KS;
+        const float4 a = *reinterpret_cast<const float4*>(reg + (ky * HW_ + li + kx) * LDW + cc * 8 + 4 * lh);
+        const float4 w = rb[it % RING];
+        if (it + RING < NIT) rb[it % RING] = *reinterpret_cast<const float4*>(wl + ((size_t)((it + RING) >> 1) * (CIN / 8) + ((it + RING) & 1)) * 64 * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();            // the wave is done reading its halo: the region becomes its partial patch [32 px][36]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) reg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[r];
+    __syncthreads();
+    const int px = threadIdx.x >> 3, c4 = threadIdx.x & 7, x = x0 + px;
+    if (x >= p.W) return;
+    float4 v = *reinterpret_cast<const float4*>(smem + px * 36 + c4 * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {               // fixed order: waves 0..3
+        const float4 u = *reinterpret_cast<const float4*>(smem + w * REGION + px * 36 + c4 * 4);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int co = half * 32 + c4 * 4;
+    if (p.bias) { const float4 bv = *reinterpret_cast<const float4*>(p.bias + co); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+    if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (p.posmap) {
+        const float4 pm = *reinterpret_cast<const float4*>(p.posmap + ((size_t)y * p.W + x) * 64 + co);
+        v.x += pm.x; v.y += pm.y; v.z += pm.z; v.w += pm.w;
+    }
+    *reinterpret_cast<float4*>(p.Y + (((size_t)b * p.H + y) * p.W + x) * 64 + co) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int KS, int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs p) {
     static_assert(COUT == 64, "COUT must be 64");
@@ -377,11 +461,25 @@ static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-int conv_fwd_launch(const ConvArgs& a_in, int KS, int CIN, int COUT, hipStream_t st) {
+// the low-latency variant pays when the throughput kernel's grid leaves most CUs idle: at most one workgroup per CU and a half
+static bool conv_lat_applies(const ConvArgs& a, int KS, int CIN) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("OCRL_CONV_LAT"); on = e ? atoi(e) : 1; }
+    return on && KS == 5 && CIN == 64 && !a.mask && a.relu <= 1 && (long long)cdiv(a.W, TW) * cdiv(a.H, TH) * a.B <= 384;
+}
+int conv_fwd_launch(const ConvArgs& a_in, int KS, int CIN, int COUT, hipStream_t st, int low_latency) {
     ConvArgs a = a_in;
     OCRL_REQUIRE(COUT == 64, "conv: COUT must be 64 (got %d)", COUT);
     OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0, "conv: empty input");
     OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)a.Wp & 15) == 0, "conv: X/Wp must be 16-byte aligned");
+    if (low_latency && conv_lat_applies(a, KS, CIN)) {
+        constexpr int smem = 4 * 5 * (TW + 4) * 20 * 4;
+        const int pi = prof_begin(PROF_CONV_OTHER, st);
+        hipLaunchKernelGGL((conv_lat_kernel<5, 64>), dim3(cdiv(a.W, TW) * a.H * a.B, 2), dim3(256), smem, st, a);
+        prof_end(pi, st);
+        OCRL_CHECK_LAUNCH("conv_lat_kernel");
+        return 0;
+    }
     if (KS == 5 && CIN == 64) return conv_fwd_cfg<5, 64>(a, st);
     if (KS == 5 && CIN == 8) return conv_fwd_cfg<5, 8>(a, st);
     if (KS == 3 && CIN == 64) return conv_fwd_cfg<3, 64>(a, st);

@@ -84,7 +84,9 @@ struct WgradArgs {
     float* part = nullptr;          // workspace, conv_wgrad_ws_floats()
     int B = 0, H = 0, W = 0;
 };
-int conv_fwd_launch(const ConvArgs& a, int KS, int CIN, int COUT, hipStream_t st);
+// low_latency: the caller's grid is small (inference at a few images): 5x5 / 64-channel forward layers whose throughput grid would leave
+// most CUs idle go to the k-split kernel (conv_lat_kernel); results differ from the throughput kernel by fp32 summation order
+int conv_fwd_launch(const ConvArgs& a, int KS, int CIN, int COUT, hipStream_t st, int low_latency = 0);
 int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st);
 size_t conv_wgrad_ws_floats(int B, int H, int W, int KS, int CIN);
 int conv_pack_launch(const float* W, float* fwd, float* bwd, int KS, int CIN, int COUT, int cin_real, hipStream_t st);

@@ -418,7 +418,7 @@ int SlateModel::conv_layer_fwd(const float* x, const float* pack, const float* b
                                int relu, const float* posmap, const float* mask, hipStream_t st) {
     ConvArgs a;
     a.X = x; a.Wp = pack; a.Y = y; a.B = Bn; a.H = Hh; a.W = Ww; a.bias = bias; a.relu = relu; a.posmap = posmap; a.mask = mask;
-    return conv_fwd_launch(a, KS, CIN, 64, st);
+    return conv_fwd_launch(a, KS, CIN, 64, st, conv_lowlat_);
 }
 int SlateModel::conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN,
                                  int cin_real, hipStream_t st) {
@@ -696,6 +696,7 @@ int SlateModel::encode(const StepInputs& in, hipStream_t st) {
     // frozen weights (ocrl_slate_freeze_weights: serving with a pre-trained encoder): the derived weight images -- convolution packs,
     // slot-attention block, position map; 8 launches, ~45 us of a 0.47 ms call at B = 1 -- are built once
     const bool need_pack = !(frozen_ && packs_valid_);
+    struct LowLat { int& f; LowLat(int& x) : f(x) { f = 1; } ~LowLat() { f = 0; } } lowlat(conv_lowlat_);      // for every fwd_encoder below
     if (!graph) {
         if (need_pack) RC(pack_weights(st, true));
         packs_valid_ = frozen_;

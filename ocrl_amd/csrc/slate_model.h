@@ -119,6 +119,7 @@ private:
     StepInputs last_;
     float pdrop_ = 0.f;
     bool have_fwd_ = false;
+    int conv_lowlat_ = 0;           // set around the encoder of encode(): small grids take the low-latency convolution
     bool frozen_ = false, packs_valid_ = false;   // freeze_weights(): encode() re-uses the derived weight images (serving: the parameters do not change)
     bool have_enc_ = false;         // the last call was encode(): its activations are what encode_backward() differentiates
     bool enc_only_grads_ = false;   // the gradient buffer holds an encode_backward(): only the encoder tensors have gradients

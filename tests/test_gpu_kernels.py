@@ -109,6 +109,29 @@ def test_conv_fwd(L, B, S, cin, ks):
     assert e < TOL
 
 
+@pytest.mark.parametrize("B,H,W,relu", [(1, 64, 64, 1), (2, 16, 16, 1), (3, 20, 44, 0), (1, 128, 128, 1), (8, 64, 64, 1), (1, 7, 33, 1)])
+def test_conv_fwd_low_latency_variant(L, B, H, W, relu):
+    """ocrl_conv2d_fwd_lowlat: the k-split kernel the inference path (encode at a few images) uses for the 5x5 / 64-channel layers --
+    ragged widths (a partial 32-pixel segment), heights that are no multiple of the throughput kernel's 4-row tile, with and without
+    ReLU -- against F.conv2d in fp64 and against the throughput kernel (same arithmetic, other summation order)"""
+    g = torch.Generator().manual_seed(B * H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 5, 5, generator=g) / 40.0
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=2)
+    if relu:
+        ref = torch.relu(ref)
+    xd, wd, bd = dev(nhwc(x)), dev(w), dev(b)
+    y, y0 = torch.full((B, H, W, 64), float("nan"), device="cuda"), torch.empty(B, H, W, 64, device="cuda")
+    ws = torch.empty(25 * 64 * 64, device="cuda")
+    L.check(L.lib().ocrl_conv2d_fwd_lowlat(P(xd), P(wd), P(bd), P(y), B, H, W, 64, 64, 5, relu, P(ws), None))
+    L.check(L.lib().ocrl_conv2d_fwd(P(xd), P(wd), P(bd), P(y0), B, H, W, 64, 64, 5, relu, P(ws), None))
+    torch.cuda.synchronize()
+    e, e0 = relerr(y.cpu().permute(0, 3, 1, 2), ref), relerr(y.cpu(), y0.cpu())
+    log(f"conv fwd low-latency B{B} {H}x{W} relu{relu}: vs fp64 {e:.2e}, vs the throughput kernel {e0:.2e}")
+    assert torch.isfinite(y).all() and e < TOL and e0 < TOL
+
+
 @pytest.mark.parametrize("B,S,ks", [(2, 16, 5), (2, 32, 5), (2, 12, 3)])
 def test_conv_bwd_data(L, B, S, ks):
     g = torch.Generator().manual_seed(B * S + ks)

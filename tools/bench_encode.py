@@ -19,6 +19,8 @@ for S in (64, 128):
     model.to("cuda:0")
     model.eval()
     pool = Transformer_Module(model.rep_dim, model.num_slots, POOL).cuda().eval()
+    if os.environ.get("FROZEN", "1") != "0":
+        model._module.freeze_weights(True)      # serving: constant weights, derived weight images built once (OCRExtractor with a pre-trained encoder)
     for B in (1, 8, 32):
         obs = torch.rand(B, 3, S, S, device="cuda")
         for _ in range(5):
