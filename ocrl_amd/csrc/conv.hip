@@ -461,11 +461,11 @@ static int conv_fwd_cfg(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-// the low-latency variant pays when the throughput kernel's grid leaves most CUs idle: at most one workgroup per CU and a half
+// the low-latency variant pays when the throughput kernel's grid leaves most CUs idle: fewer than ~0.6 workgroups per CU (measured: 64x64, B = 8 = 256 tiles is already faster on the throughput kernel)
 static bool conv_lat_applies(const ConvArgs& a, int KS, int CIN) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("OCRL_CONV_LAT"); on = e ? atoi(e) : 1; }
-    return on && KS == 5 && CIN == 64 && !a.mask && a.relu <= 1 && (long long)cdiv(a.W, TW) * cdiv(a.H, TH) * a.B <= 384;
+    return on && KS == 5 && CIN == 64 && !a.mask && a.relu <= 1 && (long long)cdiv(a.W, TW) * cdiv(a.H, TH) * a.B <= 160;
 }
 int conv_fwd_launch(const ConvArgs& a_in, int KS, int CIN, int COUT, hipStream_t st, int low_latency) {
     ConvArgs a = a_in;

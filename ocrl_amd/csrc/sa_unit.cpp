@@ -91,14 +91,14 @@ int ocrl_slot_attention_mh_fwd(const float* x, const float* slots0, const float*
     add(w[0], 1, C, wo.ln_in_g, 0); add(w[1], 1, C, wo.ln_in_b, 0);
     add(w[2], 1, D, wo.ln_s_g, 0); add(w[3], 1, D, wo.ln_s_b, 0);
     add(w[4], 1, D, wo.ln_m_g, 0); add(w[5], 1, D, wo.ln_m_b, 0);
-    add(w[6], D, D, wo.Wq, 0); add(w[6], D, D, wo.WqT, 1);
-    add(w[7], D, C, wo.Wk, 0); add(w[7], D, C, wo.WkT, 1);
-    add(w[8], D, C, wo.Wv, 0); add(w[8], D, C, wo.WvT, 1);
-    add(w[9], 3 * D, D, wo.Wih, 0); add(w[9], 3 * D, D, wo.WihT, 1);
-    add(w[10], 3 * D, D, wo.Whh, 0); add(w[10], 3 * D, D, wo.WhhT, 1);
+    add(w[6], D, D, wo.Wq, 2); add(w[6], D, D, wo.WqT, 3);
+    add(w[7], D, C, wo.Wk, 2); add(w[7], D, C, wo.WkT, 3);
+    add(w[8], D, C, wo.Wv, 2); add(w[8], D, C, wo.WvT, 3);
+    add(w[9], 3 * D, D, wo.Wih, 2); add(w[9], 3 * D, D, wo.WihT, 3);
+    add(w[10], 3 * D, D, wo.Whh, 2); add(w[10], 3 * D, D, wo.WhhT, 3);
     add(w[11], 1, 3 * D, wo.bih, 0); add(w[12], 1, 3 * D, wo.bhh, 0);
-    add(w[13], H, D, wo.W0, 0); add(w[13], H, D, wo.W0T, 1); add(w[14], 1, H, wo.b0, 0);
-    add(w[15], D, H, wo.W2, 0); add(w[15], D, H, wo.W2T, 1); add(w[16], 1, D, wo.b2, 0);
+    add(w[13], H, D, wo.W0, 2); add(w[13], H, D, wo.W0T, 3); add(w[14], 1, H, wo.b0, 0);
+    add(w[15], D, H, wo.W2, 2); add(w[15], D, H, wo.W2T, 3); add(w[16], 1, D, wo.b2, 0);
     OCRL_HIP(hipMemcpyAsync(ws + l.table, e, n * sizeof(PackEntry), hipMemcpyHostToDevice, st));
     OCRL_HIP(hipStreamSynchronize(st));            // `e` lives on this stack frame
     int mx = 3 * D * D;

@@ -322,14 +322,14 @@ int SlateModel::bind(float* p, float* g, float* m, float* v, void* ws, size_t ws
     e(sa + "norm_inputs.weight", 1, C, wo.ln_in_g, 0); e(sa + "norm_inputs.bias", 1, C, wo.ln_in_b, 0);
     e(sa + "norm_slots.weight", 1, D, wo.ln_s_g, 0); e(sa + "norm_slots.bias", 1, D, wo.ln_s_b, 0);
     e(sa + "norm_mlp.weight", 1, D, wo.ln_m_g, 0); e(sa + "norm_mlp.bias", 1, D, wo.ln_m_b, 0);
-    e(sa + "project_q.weight", D, D, wo.Wq, 0); e(sa + "project_q.weight", D, D, wo.WqT, 1);
-    e(sa + "project_k.weight", D, C, wo.Wk, 0); e(sa + "project_k.weight", D, C, wo.WkT, 1);
-    e(sa + "project_v.weight", D, C, wo.Wv, 0); e(sa + "project_v.weight", D, C, wo.WvT, 1);
-    e(sa + "gru.weight_ih", 3 * D, D, wo.Wih, 0); e(sa + "gru.weight_ih", 3 * D, D, wo.WihT, 1);
-    e(sa + "gru.weight_hh", 3 * D, D, wo.Whh, 0); e(sa + "gru.weight_hh", 3 * D, D, wo.WhhT, 1);
+    e(sa + "project_q.weight", D, D, wo.Wq, 2); e(sa + "project_q.weight", D, D, wo.WqT, 3);
+    e(sa + "project_k.weight", D, C, wo.Wk, 2); e(sa + "project_k.weight", D, C, wo.WkT, 3);
+    e(sa + "project_v.weight", D, C, wo.Wv, 2); e(sa + "project_v.weight", D, C, wo.WvT, 3);
+    e(sa + "gru.weight_ih", 3 * D, D, wo.Wih, 2); e(sa + "gru.weight_ih", 3 * D, D, wo.WihT, 3);
+    e(sa + "gru.weight_hh", 3 * D, D, wo.Whh, 2); e(sa + "gru.weight_hh", 3 * D, D, wo.WhhT, 3);
     e(sa + "gru.bias_ih", 1, 3 * D, wo.bih, 0); e(sa + "gru.bias_hh", 1, 3 * D, wo.bhh, 0);
-    e(sa + "mlp.0.weight", H, D, wo.W0, 0); e(sa + "mlp.0.weight", H, D, wo.W0T, 1); e(sa + "mlp.0.bias", 1, H, wo.b0, 0);
-    e(sa + "mlp.2.weight", D, H, wo.W2, 0); e(sa + "mlp.2.weight", D, H, wo.W2T, 1); e(sa + "mlp.2.bias", 1, D, wo.b2, 0);
+    e(sa + "mlp.0.weight", H, D, wo.W0, 2); e(sa + "mlp.0.weight", H, D, wo.W0T, 3); e(sa + "mlp.0.bias", 1, H, wo.b0, 0);
+    e(sa + "mlp.2.weight", D, H, wo.W2, 2); e(sa + "mlp.2.weight", D, H, wo.W2T, 3); e(sa + "mlp.2.bias", 1, D, wo.b2, 0);
     sa_pack_n_ = (int)ent.size();
     sa_pack_max_ = 3 * D * D;
     OCRL_REQUIRE(sa_pack_n_ <= 64, "pack table overflow");

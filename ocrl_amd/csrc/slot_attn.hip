@@ -55,8 +55,12 @@ __device__ inline float redg_sum(float v) {           // over the 4 lanes of one
 // output; per 16 values of e a lane issues one float4 weight load (the k-contiguous orientation of the weight, L2 resident) and
 // one ds_read_b128 of its slot row and feeds 4 MFMAs — the slot-side products take microseconds instead of walking e serially.
 // Ends with a workgroup barrier.
+// The weights are stored tiled for this loop (pack_kernel modes 2 / 3): matrix Wn[col][e] (col < NCt, e < Et) as [col / 16][e / 16][lane][4]
+// with lane = 16 * ((e % 16) / 4) + col % 16 -- the float4 a lane needs for 16 output columns x 16 values of e is one contiguous 1 KiB
+// block per load instruction (the row-major form touched 16 half-used cache lines per instruction).  A job may address a sub-block:
+// column tiles from t0, k-steps from s0 (the per-head products of multi-head slot attention).
 struct MvJob {           // one product of the slot-side chain: out[j][col] = scale * in[j] . Wn[col] + bias[col]
-    const float* Wn; int ldw, E, NC; const float* in; int ldin; float* out; int ldout; const float* bias; float scale;
+    const float* Wt; int nkt, t0, s0, E, NC; const float* in; int ldin; float* out; int ldout; const float* bias; float scale;
 };
 // one 16-column output tile of a job (all K rows)
 template <int K>
@@ -65,7 +69,7 @@ __device__ __forceinline__ void mv_tile(const MvJob& J, int tile) {
     const int nks = J.E >> 4;
     const float* arow = J.in + (li < K ? li : 0) * J.ldin + 4 * g;
     const int col = tile * 16 + li;
-    const float* wrow = J.Wn + (size_t)col * J.ldw + 4 * g;
+    const float* wrow = J.Wt + ((size_t)(J.t0 + tile) * J.nkt + J.s0) * 256 + lane * 4;
     f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     // the weight row is fetched twelve k-steps (192 values of e) at a time, all loads issued before the first MFMA: one L2 round
     // trip per 192 e instead of one per 16
@@ -73,7 +77,7 @@ __device__ __forceinline__ void mv_tile(const MvJob& J, int tile) {
         float4 bw[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u)
-            if (s0 + u < nks) bw[u] = *reinterpret_cast<const float4*>(wrow + 16 * (s0 + u));
+            if (s0 + u < nks) bw[u] = *reinterpret_cast<const float4*>(wrow + 256 * (s0 + u));
         __builtin_amdgcn_sched_barrier(0);          // keep the loads above: the scheduler otherwise sinks them next to their MFMAs (2 in flight)
 #pragma unroll
         for (int u = 0; u < 12; ++u)
@@ -96,10 +100,10 @@ __device__ __forceinline__ void mv_tile(const MvJob& J, int tile) {
 // output; per 16 values of e a lane issues one float4 weight load (the k-contiguous orientation of the weight, L2 resident) and
 // one ds_read_b128 of its slot row and feeds 4 MFMAs.  Ends with a workgroup barrier.
 template <int K>
-__device__ __forceinline__ void matvec(const float* __restrict__ Wn, int ldw, int E, int NC, const float* in, int ldin, float* out, int ldout,
+__device__ __forceinline__ void matvec(const float* __restrict__ Wt, int nkt, int t0, int s0, int E, int NC, const float* in, int ldin, float* out, int ldout,
                                        const float* __restrict__ bias, float scale) {
     const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const MvJob J = {Wn, ldw, E, NC, in, ldin, out, ldout, bias, scale};
+    const MvJob J = {Wt, nkt, t0, s0, E, NC, in, ldin, out, ldout, bias, scale};
     for (int tile = wv; tile < (NC >> 4); tile += nw) mv_tile<K>(J, tile);
     __syncthreads();
 }
@@ -478,10 +482,10 @@ __device__ __forceinline__ void sa_phase_a(const SaFwdLds<K, G>& L, const SlotAt
         if (sv.base) rows_put(sB, sv, so.sprev, j0, kv, D);
         ln_rows(sB, L.sn, W + wo.ln_s_g, W + wo.ln_s_b, KB, D);
         __syncthreads();
-        matvec<KB>(W + wo.Wq, D, D, D, L.sn, D, L.q, D, nullptr, 1.f);
+        matvec<KB>(W + wo.Wq, D / 16, 0, 0, D, D, L.sn, D, L.q, D, nullptr, 1.f);
         // q'_h = scale q[:, head h] Wk[head h, :]  (one head: the whole row)
 #pragma unroll 1
-        for (int h = 0; h < NH; ++h) matvec<KB>(W + wo.WkT + h * dh, D, dh, C, L.q + h * dh, D, L.qp + (h * KP + j0) * C, C, nullptr, p.scale);
+        for (int h = 0; h < NH; ++h) matvec<KB>(W + wo.WkT, D / 16, 0, h * dh / 16, dh, C, L.q + h * dh, D, L.qp + (h * KP + j0) * C, C, nullptr, p.scale);
         if (sv.base) {
             rows_put(L.sn, sv, so.sn, j0, kv, D);
             rows_put(L.q, sv, so.q, j0, kv, D);
@@ -550,9 +554,9 @@ __device__ __forceinline__ void sa_phase_u(const SaFwdLds<K, G>& L, const SlotAt
         float* sB = L.s + j0 * D;
         // updates[:, head h] = U'_h Wv[head h, :]^T
 #pragma unroll 1
-        for (int h = 0; h < NH; ++h) matvec<KB>(W + wo.Wv + h * dh * C, C, C, dh, L.up + (h * KP + j0) * C, C, u + h * dh, D, nullptr, 1.f);
+        for (int h = 0; h < NH; ++h) matvec<KB>(W + wo.Wv, C / 16, h * dh / 16, 0, C, dh, L.up + (h * KP + j0) * C, C, u + h * dh, D, nullptr, 1.f);
         {
-            const MvJob ji = {W + wo.Wih, D, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f}, jh = {W + wo.Whh, D, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f};
+            const MvJob ji = {W + wo.Wih, D / 16, 0, 0, D, 3 * D, u, D, gi, 3 * D, W + wo.bih, 1.f}, jh = {W + wo.Whh, D / 16, 0, 0, D, 3 * D, sB, D, gh, 3 * D, W + wo.bhh, 1.f};
             matvec2<KB>(ji, jh);
         }
         for (int i = tid; i < KB * D; i += nt) {
@@ -571,10 +575,10 @@ __device__ __forceinline__ void sa_phase_u(const SaFwdLds<K, G>& L, const SlotAt
         __syncthreads();
         ln_rows(q, sn, W + wo.ln_m_g, W + wo.ln_m_b, KB, D);      // sn = m
         __syncthreads();
-        matvec<KB>(W + wo.W0, D, D, H, sn, D, hid, H, W + wo.b0, 1.f);
+        matvec<KB>(W + wo.W0, D / 16, 0, 0, D, H, sn, D, hid, H, W + wo.b0, 1.f);
         for (int i = tid; i < KB * H; i += nt) hid[i] = fmaxf(hid[i], 0.f);
         __syncthreads();
-        matvec<KB>(W + wo.W2, H, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
+        matvec<KB>(W + wo.W2, H / 16, 0, 0, H, D, hid, H, u, D, W + wo.b2, 1.f);      // u = mlp out
         for (int i = tid; i < kv * D; i += nt) sB[i] = q[i] + u[i];
         if (sv.base) {
             rows_put(sn, sv, so.m, j0, kv, D);
@@ -1019,7 +1023,7 @@ __device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const Slot
         rows_put(dsB, gr, go.out, j0, kv, D);
         rows_get(t0, sv, so.sg, j0, kv, D);
         for (int i = kv * D + tid; i < KB * D; i += nt) t0[i] = 0.f;                // padding rows: defined values for the LayerNorm statistics
-        matvec<KB>(W + wo.W2T, D, D, H, dsB, D, dhid, H, nullptr, 1.f);          // dhid[h] = sum_d ds[d] W2[d][h]
+        matvec<KB>(W + wo.W2T, D / 16, 0, 0, D, H, dsB, D, dhid, H, nullptr, 1.f);          // dhid[h] = sum_d ds[d] W2[d][h]
         for (int i = tid; i < kv * H; i += nt) {
             const int j = i / H, c = i - j * H;
             const float v = sv(j0 + j)[so.hid + c] > 0.f ? dhid[i] : 0.f;
@@ -1027,7 +1031,7 @@ __device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const Slot
             gr(j0 + j)[go.hid + c] = v;
         }
         __syncthreads();
-        matvec<KB>(W + wo.W0T, H, H, D, dhid, H, t1, D, nullptr, 1.f);           // dm[e] = sum_h dhid[h] W0[h][e]
+        matvec<KB>(W + wo.W0T, H / 16, 0, 0, H, D, dhid, H, t1, D, nullptr, 1.f);           // dm[e] = sum_h dhid[h] W0[h][e]
         ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_m_g, dg_m, db_m, kv, D);           // ds = d s_gru
         __syncthreads();
         // ---- GRU backward
@@ -1047,7 +1051,7 @@ __device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const Slot
         rows_put(dgi, gr, go.gi, j0, kv, 3 * D);
         rows_put(dgh, gr, go.gh, j0, kv, 3 * D);
         {   // du[e] = sum_g dgi[g] Wih[g][e]  and  dh via the recurrent weights, one pass
-            const MvJob ji = {W + wo.WihT, 3 * D, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f}, jh = {W + wo.WhhT, 3 * D, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f};
+            const MvJob ji = {W + wo.WihT, 3 * D / 16, 0, 0, 3 * D, D, dgi, 3 * D, t1, D, nullptr, 1.f}, jh = {W + wo.WhhT, 3 * D / 16, 0, 0, 3 * D, D, dgh, 3 * D, t0, D, nullptr, 1.f};
             matvec2<KB>(ji, jh);
         }
         for (int i = tid; i < kv * D; i += nt) t2B[i] += t0[i];
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void sa_bwd_part1(const SaBwdLds<K, G>& L, const Slot
         // ---- u = up Wv^T
 #pragma unroll 1
         for (int h = 0; h < NH; ++h)          // dU'_h[c] = sum_{d in head h} du[d] Wv[d][c]
-            matvec<KB>(W + wo.WvT + h * dh, D, dh, C, t1 + h * dh, D, L.dup + (h * KP + j0) * C, C, nullptr, 1.f);
+            matvec<KB>(W + wo.WvT, D / 16, 0, h * dh / 16, dh, C, t1 + h * dh, D, L.dup + (h * KP + j0) * C, C, nullptr, 1.f);
     }
     for (int h = 0; h < NH; ++h) rows_get(L.qp + h * KP * C, sv, so.qp + h * C, 0, nvalid, C);
     for (int i = tid; i < KV * C; i += nt)
@@ -1124,11 +1128,11 @@ __device__ __forceinline__ void sa_bwd_part2(const SaBwdLds<K, G>& L, const Slot
         // ---- q' = scale q Wk  ->  dq[d] = scale sum_c dqp[c] Wk[d][c] ;  q = sn Wq^T  ->  dsn[e] = sum_d dq[d] Wq[d][e]
 #pragma unroll 1
         for (int h = 0; h < NH; ++h)          // dq[:, head h] = scale dq'_h Wk[head h, :]^T
-            matvec<KB>(W + wo.Wk + h * dh * C, C, C, dh, dqp + (h * KP + j0) * C, C, t1 + h * dh, D, nullptr, p.scale);   // t1 = dq
+            matvec<KB>(W + wo.Wk, C / 16, h * dh / 16, 0, C, dh, dqp + (h * KP + j0) * C, C, t1 + h * dh, D, nullptr, p.scale);   // t1 = dq
         rows_put(t1, gr, go.q, j0, kv, D);
         rows_get(t0, sv, so.sprev, j0, kv, D);
         for (int i = kv * D + tid; i < KB * D; i += nt) t0[i] = 0.f;
-        matvec<KB>(W + wo.WqT, D, D, D, t1, D, dsB, D, nullptr, 1.f);                 // ds = dsn
+        matvec<KB>(W + wo.WqT, D / 16, 0, 0, D, D, t1, D, dsB, D, nullptr, 1.f);                 // ds = dsn
         for (int i = tid; i < kv * D; i += nt) { t1[i] = dsB[i]; dsB[i] = L.t2[j0 * D + i]; }
         __syncthreads();
         ln_rows_bwd(t1, t0, dsB, 1, W + wo.ln_s_g, dg_s, db_s, kv, D);                      // ds = dh + LN_s backward
@@ -1447,7 +1451,14 @@ __global__ void pack_kernel(const PackEntry* __restrict__ ent, float* __restrict
     const PackEntry e = ent[blockIdx.y];
     const int n = e.rows * e.cols;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (e.transpose) {      // dst[c][r] = src[r][c], i enumerates dst
+        if (e.transpose >= 2) {     // tiled for the slot-side matrix products (MvJob): Wn[col][k] -> [col / 16][k / 16][16 * ((k % 16) / 4) + col % 16][k % 4]
+            // mode 2: Wn = src ([rows = columns of the product][cols = k]);  mode 3: Wn = src^T
+            const int NCt = e.transpose == 2 ? e.rows : e.cols, Et = e.transpose == 2 ? e.cols : e.rows, nks = Et >> 4;
+            const int j = i & 3, lane = (i >> 2) & 63, rest = i >> 8, s = rest % nks, tile = rest / nks;
+            const int col = tile * 16 + (lane & 15), k = s * 16 + (lane >> 4) * 4 + j;
+            (void)NCt;
+            dst[e.dst_off + i] = e.transpose == 2 ? e.src[col * Et + k] : e.src[k * e.cols + col];
+        } else if (e.transpose) {      // dst[c][r] = src[r][c], i enumerates dst
             const int c = i / e.rows, r = i - c * e.rows;
             dst[e.dst_off + i] = e.src[r * e.cols + c];
         } else {
