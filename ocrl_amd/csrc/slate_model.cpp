@@ -466,6 +466,7 @@ int SlateModel::fwd_encoder(const StepInputs& in, hipStream_t st, int fork_dvae)
     SlotAttnArgs a;
     a.B = B; a.N = N; a.C = C; a.K = K; a.D = D; a.H = H; a.I = I; a.NH = SH; a.eps = 1e-8f; a.scale = 1.0f / sqrtf((float)(D / SH));
     a.x = x_; a.slots0 = slots0_; a.wts = sa_wts_; a.slots = slots_; a.attn = attn_; a.attn_heads = attn_heads_; a.save = sa_save_;
+    if (conv_lowlat_ && frozen_) a.save = nullptr;       // encode() of a frozen encoder: no backward can follow, the saved-activation rows are not written
     a.xchg = sa_xchg_; a.parts = sa_parts_;
     a.phase = 1;
     RC(slot_attn_launch(a, 0, st));
@@ -747,6 +748,7 @@ void SlateModel::clear_encode_graphs() {
 
 int SlateModel::encode_backward(const float* dslots, hipStream_t st) {
     OCRL_REQUIRE(have_enc_, "encode_backward: call encode first (its activations are what is differentiated)");
+    OCRL_REQUIRE(!frozen_, "encode_backward: the weights are frozen (ocrl_slate_freeze_weights): encode() kept no activations");
     OCRL_REQUIRE(g_ && dslots, "encode_backward: no gradient buffer bound / null dslots");
     RC(fill_launch(g_, flat_size_, 0.f, st));
     RC(copy_launch(dslots, gslots_, (long long)last_.B * K * D, st));
