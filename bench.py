@@ -47,7 +47,7 @@ def _host_cores():
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(obs_size, batch, steps, use_bcdec=False):
+def cpu_baseline(obs_size, batch, steps, use_bcdec=False, num_slots=6):
     """the CPU oracle's update() (port of ocrs/slate/slate.py:53-69 + ocrs/base.py:60-74) on the host cores: SURVEY.md §8(d) —
     batch 8, train mode dropout 0.1, 1 warm-up + >= 3 timed steps, median"""
     from oracle import slate_oracle as O
@@ -55,7 +55,7 @@ def cpu_baseline(obs_size, batch, steps, use_bcdec=False):
     cores = _host_cores()
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: oracle update() on {cores} host threads, batch {batch}, {steps} timed steps", file=sys.stderr, flush=True)
-    cfg = O.default_cfg(obs_size=obs_size, num_slots=6, num_iterations=3, use_bcdec=use_bcdec)
+    cfg = O.default_cfg(obs_size=obs_size, num_slots=num_slots, num_iterations=3, use_bcdec=use_bcdec)
     tr = O.OracleTrainer(cfg, O.formula_params(cfg))
     obs = scenes_to_obs(random_sprite_scenes(batch, obs_size, seed=123))
     times = []
@@ -69,7 +69,7 @@ def cpu_baseline(obs_size, batch, steps, use_bcdec=False):
     t = sorted(times[1:])[len(times[1:]) // 2]
     name = "Slot-Attention (use_bcdec)" if use_bcdec else "SLATE"
     return {"value": round(batch / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle update() {name} {obs_size}x{obs_size}/6 slots/3 iters, batch {batch}, train mode dropout 0.1, "
+            "sample": f"oracle update() {name} {obs_size}x{obs_size}/{num_slots} slots/3 iters, batch {batch}, train mode dropout 0.1, "
                       f"1 warm-up + {steps} timed steps, median {t:.2f} s/step (an un-tuned PyTorch-CPU port of the reference step; the reference "
                       f"modules themselves measured 1.33 images/s on 8 threads for SLATE 128x128, SURVEY.md §6)"}
 
@@ -390,7 +390,7 @@ def main():
                                          "materialised k|v form would move 75.5 MB/img forward); fwd / bwd = the chain on its own at the same shape, HIP events "
                                          "around its launches; pmc = matrix-pipe busy fraction / resident waves per SIMD / HBM bytes per launch from rocprofv3 counters"}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec))
+        out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec), num_slots=int(ocr.slotattr.num_slots))
     if args.rehearse_on_one_gpu:
         out["rehearsal"] = "all ranks on cuda:0, gradients reduced over gloo: exercises the launch / barrier / reduction plumbing only, not a measurement"
     print(json.dumps(out))
