@@ -148,6 +148,19 @@ int ocrl_conv2d_fwd_lowlat(const float* x, const float* w, const float* bias, fl
     a.X = x; a.Wp = ws; a.Y = y; a.B = B; a.H = H; a.W = W; a.bias = bias; a.relu = relu;
     return conv_fwd_launch(a, ks, cin_pad, 64, ST(stream), 1);
 }
+size_t ocrl_conv2d_x3_ws_floats(void) { return 2 * conv_x3_pack_floats(); }
+int ocrl_conv2d_fwd_x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int relu, float* ws, void* stream) {
+    if (conv_pack_x3_launch(w, ws, nullptr, ST(stream))) return 1;
+    ConvArgs a;
+    a.X = x; a.Y = y; a.B = B; a.H = H; a.W = W; a.bias = bias; a.relu = relu;
+    return conv_x3_launch(a, ws, ST(stream));
+}
+int ocrl_conv2d_bwd_data_x3(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, float* ws, void* stream) {
+    if (conv_pack_x3_launch(w, ws, ws + conv_x3_pack_floats(), ST(stream))) return 1;
+    ConvArgs a;
+    a.X = dy; a.Y = dx; a.B = B; a.H = H; a.W = W; a.mask = mask;
+    return conv_x3_launch(a, ws + conv_x3_pack_floats(), ST(stream));
+}
 int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream) {
     float* bw = ws + (size_t)ks * ks * 64 * 64;
     if (conv_pack_launch(w, ws, bw, ks, 64, 64, 64, ST(stream))) return 1;

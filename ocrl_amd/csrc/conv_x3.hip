@@ -1,0 +1,246 @@
+// EXPLORATORY (OCRL_CONV_X3=1, never the default, never the headline bench line): the 5x5 / 64-channel convolution on the bf16 matrix
+// pipe with fp32-equivalent split precision.  gfx950 has no xf32 / tf32 MFMA and the fp32 MFMA runs at 1/16 of the bf16 rate, so the
+// fp32 convolutions (0.87 of that peak) cannot get faster on it.  Here every fp32 operand is written as the EXACT sum of three bf16
+// numbers, x = h + m + l (h = the top 8 significant bits by truncation, m the next 8, l the last 8: both subtractions are exact in
+// fp32), and x*w is accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 products
+//      h*h' + h*m' + m*h' + m*m' + h*l' + l*h'
+// -- the three dropped terms (m*l', l*m', l*l') are below 2^-24 of |x*w|, the rounding of an fp32 product.  Six bf16 products of 16 k
+// each cost 6 x 32 cycles for what eight fp32 32x32x2 products need 8 x 64 cycles for: 2.67x fewer matrix-pipe cycles.
+//
+// Kernel shape: 8 rows x 32 pixels per workgroup, a wave owns two rows (two 32-pixel M blocks) x 64 output channels, so one weight
+// fragment feeds two MFMAs per product and the packed weights (three bf16 planes, [tap][chunk][n-block][plane][lane][8]) can stream
+// from L2 at 32 B/clk/CU.  The halo stays fp32 in LDS (12 x 36 pixels x 68 floats = 117.5 KB, one workgroup per CU) and an A
+// fragment (8 channels of a pixel) is split into its three bf16 planes in registers right before its MFMAs (bit masks, two exact
+// subtractions and three v_perm_b32 per pair of values, issued in the shadow of the MFMAs).  Same epilogue features as
+// conv_fwd_kernel (bias, ReLU / ELU, position map, activation mask), so it also serves the backward-data pass.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define X3_TH 8
+#define X3_TW 32
+#define X3_KS 5
+#define X3_HW (X3_TW + X3_KS - 1)
+#define X3_HH (X3_TH + X3_KS - 1)
+#define X3_LDH 68
+#define X3_NCH 4          // 16-channel chunks of the 64 input channels
+
+__device__ __forceinline__ uint32_t x3_hi(float x) { return __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u; }
+// eight fp32 values (two float4) -> three planes of eight bf16 (h, m, l), x = h + m + l exactly
+__device__ __forceinline__ void x3_split(const float4& a, const float4& b, uint4& h, uint4& m, uint4& l) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = x[2 * p], x1 = x[2 * p + 1];
+        const uint32_t h0 = x3_hi(x0), h1 = x3_hi(x1);
+        ph[p] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);                       // {h1.hi16, h0.hi16}
+        const float r0 = x0 - __builtin_bit_cast(float, h0), r1 = x1 - __builtin_bit_cast(float, h1);
+        const uint32_t m0 = x3_hi(r0), m1 = x3_hi(r1);
+        pm[p] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+        const float q0 = r0 - __builtin_bit_cast(float, m0), q1 = r1 - __builtin_bit_cast(float, m1);
+        pl[p] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q1), __builtin_bit_cast(uint32_t, q0), 0x07060302u);
+    }
+    h = make_uint4(ph[0], ph[1], ph[2], ph[3]); m = make_uint4(pm[0], pm[1], pm[2], pm[3]); l = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+__global__ __launch_bounds__(256, 1) void conv_x3_kernel(ConvArgs p, const uint4* __restrict__ Wp3) {
+    constexpr int KS = X3_KS, P = KS / 2, HW_ = X3_HW, HH_ = X3_HH, LDH = X3_LDH, NCH = X3_NCH, CIN = 64, COUT = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tiles_x = (p.W + X3_TW - 1) / X3_TW, tiles_y = (p.H + X3_TH - 1) / X3_TH;
+    int bid = blockIdx.x;
+    {   // contiguous runs of tiles per XCD (vertically adjacent tiles share halo rows in that XCD's L2), as conv_fwd_kernel
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int b = bid;
+    const int x0 = tx * X3_TW, y0 = ty * X3_TH;
+    {   // halo tile -> LDS in three batches (loads of a batch issued before its stores)
+        constexpr int F4 = CIN / 4, TOTAL = HH_ * HW_ * F4, NB = 9, NBATCH = (TOTAL + 256 * NB - 1) / (256 * NB);
+        const float* Xb = p.X + (size_t)b * p.H * p.W * CIN;
+#pragma unroll 1
+        for (int bt = 0; bt < NBATCH; ++bt) {
+            float4 hv[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = threadIdx.x + (bt * NB + i) * 256;
+                const int c4 = idx % F4, hp = idx / F4;
+                const int hx = hp % HW_, hy = hp / HW_;
+                const int y = y0 - P + hy, x = x0 - P + hx;
+                hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < TOTAL && y >= 0 && y < p.H && x >= 0 && x < p.W) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * p.W + x) * CIN + c4 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int idx = threadIdx.x + (bt * NB + i) * 256;
+                if (idx < TOTAL) *reinterpret_cast<float4*>(smem + (idx / F4) * LDH + (idx % F4) * 4) = hv[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // operand rings of one tap (NCH slots): slot c holds the raw A values (two rows) and the six B fragments of chunk c; after its
+    // MFMAs are issued it is refilled with the next tap's chunk c, three chunks ahead of its use
+    const uint4* wl = Wp3 + lane;
+    float4 ra[NCH][2][2];
+    uint4 rb[NCH][2][3];
+    const float* abase = smem + ((2 * wave) * HW_ + li) * LDH + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) rb[c][n][pl] = wl[((c * 2 + n) * 3 + pl) * 64];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ra[c][m][0] = *reinterpret_cast<const float4*>(abase + m * HW_ * LDH + c * 16);
+            ra[c][m][1] = *reinterpret_cast<const float4*>(abase + m * HW_ * LDH + c * 16 + 4);
+        }
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int tn = tap + 1;
+        const bool more = tn < KS * KS;
+        const int ky = more ? tn / KS : 0, kx = more ? tn - (tn / KS) * KS : 0;
+        const float* an = abase + (ky * HW_ + kx) * LDH;
+        const uint4* wn = wl + (size_t)(more ? tn : 0) * NCH * 2 * 3 * 64;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint4 ah[2], am[2], al[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) x3_split(ra[c][m][0], ra[c][m][1], ah[m], am[m], al[m]);
+            uint4 bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { bh[n] = rb[c][n][0]; bm[n] = rb[c][n][1]; bl[n] = rb[c][n][2]; }
+            // refill the slot (after the last tap this harmlessly re-reads tap 0: no branch in the loop body)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) rb[c][n][pl] = wn[((c * 2 + n) * 3 + pl) * 64];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ra[c][m][0] = *reinterpret_cast<const float4*>(an + m * HW_ * LDH + c * 16);
+                ra[c][m][1] = *reinterpret_cast<const float4*>(an + m * HW_ * LDH + c * 16 + 4);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    f32x16 a_ = acc[m][n];
+                    a_ = X3_MFMA(al[m], bh[n], a_);          // small terms first
+                    a_ = X3_MFMA(ah[m], bl[n], a_);
+                    a_ = X3_MFMA(am[m], bm[n], a_);
+                    a_ = X3_MFMA(am[m], bh[n], a_);
+                    a_ = X3_MFMA(ah[m], bm[n], a_);
+                    a_ = X3_MFMA(ah[m], bh[n], a_);
+                    acc[m][n] = a_;
+                }
+        }
+    }
+
+    // ---- epilogue (conv_fwd_kernel's): each (wave, row) tile of 32 pixels x 64 channels through an LDS patch, float4 rows out
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        float* patch = smem + (wave * 2 + m) * 32 * (COUT + 4);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * (COUT + 4) + tn * 32 + li] = acc[m][tn][r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c4 = lane & 15, px0 = lane >> 4;
+    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int y = y0 + 2 * wave + m;
+        if (y >= p.H) continue;
+        const float* patch = smem + (wave * 2 + m) * 32 * (COUT + 4);
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int px = ps * 4 + px0, x = x0 + px;
+            if (x >= p.W) continue;
+            float4 v = *reinterpret_cast<const float4*>(patch + px * (COUT + 4) + c4 * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (p.relu == 2) {
+                v.x = v.x > 0.f ? v.x : __expf(v.x) - 1.f; v.y = v.y > 0.f ? v.y : __expf(v.y) - 1.f;
+                v.z = v.z > 0.f ? v.z : __expf(v.z) - 1.f; v.w = v.w > 0.f ? v.w : __expf(v.w) - 1.f;
+            }
+            const size_t pix = ((size_t)b * p.H + y) * p.W + x;
+            if (p.posmap) {
+                const float4 pm = *reinterpret_cast<const float4*>(p.posmap + ((size_t)y * p.W + x) * COUT + c4 * 4);
+                v.x += pm.x; v.y += pm.y; v.z += pm.z; v.w += pm.w;
+            }
+            if (p.mask) {
+                const float4 mk = *reinterpret_cast<const float4*>(p.mask + pix * COUT + c4 * 4);
+                const float e = p.mask_elu ? 1.f : 0.f;
+                v.x = mk.x > 0.f ? v.x : e * v.x * (mk.x + 1.f); v.y = mk.y > 0.f ? v.y : e * v.y * (mk.y + 1.f);
+                v.z = mk.z > 0.f ? v.z : e * v.z * (mk.z + 1.f); v.w = mk.w > 0.f ? v.w : e * v.w * (mk.w + 1.f);
+            }
+            *reinterpret_cast<float4*>(p.Y + pix * COUT + c4 * 4) = v;
+        }
+    }
+}
+
+// W [64][64][5][5] (reference layout) -> the split-precision packs: fwd[s][n][plane][lane] and, flipped / transposed for the
+// backward-data pass, bwd[..] (uint4 = eight bf16: k = 8*(lane>>5) + j of chunk c, column (lane & 31) of n-block n; s = tap*4 + c)
+__global__ void conv_pack_x3_kernel(const float* __restrict__ W, uint4* __restrict__ fwd, uint4* __restrict__ bwd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (s, n, lane)
+    if (i >= 25 * 4 * 2 * 64) return;
+    const int lane = i & 63, n = (i >> 6) & 1, s = i >> 7, c = s & 3, tap = s >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    float vf[8], vb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = c * 16 + 8 * h + j, col = n * 32 + r;
+        vf[j] = W[((size_t)col * 64 + k) * 25 + tap];                 // forward: B[k = ci][col = co]
+        vb[j] = W[((size_t)k * 64 + col) * 25 + (24 - tap)];          // backward data: B[k = co][col = ci] at the flipped tap
+    }
+    uint4 ph, pm, pl;
+    x3_split(make_float4(vf[0], vf[1], vf[2], vf[3]), make_float4(vf[4], vf[5], vf[6], vf[7]), ph, pm, pl);
+    const size_t o = ((size_t)(s * 2 + n) * 3) * 64 + lane;
+    fwd[o] = ph; fwd[o + 64] = pm; fwd[o + 128] = pl;
+    if (bwd) {
+        x3_split(make_float4(vb[0], vb[1], vb[2], vb[3]), make_float4(vb[4], vb[5], vb[6], vb[7]), ph, pm, pl);
+        bwd[o] = ph; bwd[o + 64] = pm; bwd[o + 128] = pl;
+    }
+}
+
+size_t conv_x3_pack_floats() { return (size_t)25 * 4 * 2 * 3 * 64 * 4; }      // floats per pack (614 KB)
+int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st) {
+    hipLaunchKernelGGL(conv_pack_x3_kernel, dim3(cdiv(25 * 4 * 2 * 64, 256)), dim3(256), 0, st, W, reinterpret_cast<uint4*>(fwd3), reinterpret_cast<uint4*>(bwd3));
+    OCRL_CHECK_LAUNCH("conv_pack_x3");
+    return 0;
+}
+int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st) {
+    OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && pack3, "conv x3: empty input / missing pack");
+    OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)pack3 & 15) == 0, "conv x3: X / pack must be 16-byte aligned");
+    constexpr int smem = X3_HH * X3_HW * X3_LDH * 4;
+    static_assert(X3_HH * X3_HW * X3_LDH >= 8 * 32 * 68, "the halo region must hold the eight epilogue patches");
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)conv_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int grid = cdiv(a.W, X3_TW) * cdiv(a.H, X3_TH) * a.B;
+    const int pi = prof_begin(PROF_CONV5, st);
+    hipLaunchKernelGGL(conv_x3_kernel, dim3(grid), dim3(256), smem, st, a, reinterpret_cast<const uint4*>(pack3));
+    prof_end(pi, st);
+    OCRL_CHECK_LAUNCH("conv_x3_kernel");
+    return 0;
+}

@@ -78,6 +78,10 @@ struct ConvArgs {
     const float* mask = nullptr;    // [B,H,W,COUT]: output zeroed where mask <= 0 (ReLU backward)
     int mask_elu = 0;               // mask holds ELU outputs: v *= (m > 0 ? 1 : m + 1)
 };
+// conv_x3.hip (exploratory): the 5x5 / 64-channel layer on the bf16 matrix pipe with every fp32 operand split exactly into three bf16
+size_t conv_x3_pack_floats();
+int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st);          // W [64][64][5][5]; bwd3 may be null
+int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st);
 struct WgradArgs {
     const float* X = nullptr;       // [B,H,W,CIN]
     const float* dY = nullptr;      // [B,H,W,COUT]

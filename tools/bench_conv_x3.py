@@ -1,0 +1,26 @@
+"""Exploratory: the 5x5 / 64-channel convolution at the benched shape (B=128, 128x128) on the fp32 MFMA kernel and on the split-precision
+bf16 kernel (csrc/conv_x3.hip), forward and backward-data: ms per launch and fp32-equivalent TFLOP/s (2*25*64*64 FLOP per output pixel)."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ocrl_amd import _lib
+L = _lib.lib(); P = _lib.ptr
+B, S = int(os.environ.get("B", 128)), int(os.environ.get("S", 128))
+x = torch.randn(B, S, S, 64, device="cuda"); w = torch.randn(64, 64, 5, 5, device="cuda") / 40; b = torch.randn(64, device="cuda")
+y = torch.empty_like(x); act = torch.randn_like(x)
+ws3 = torch.empty(L.ocrl_conv2d_x3_ws_floats(), device="cuda"); ws = torch.empty(2 * 25 * 64 * 64, device="cuda")
+flop = 2.0 * 25 * 64 * 64 * B * S * S
+def t(f, n=10):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for name, f in (("fp32 MFMA forward", lambda: _lib.check(L.ocrl_conv2d_fwd(P(x), P(w), P(b), P(y), B, S, S, 64, 64, 5, 1, P(ws), None))),
+                ("3xbf16 split forward", lambda: _lib.check(L.ocrl_conv2d_fwd_x3(P(x), P(w), P(b), P(y), B, S, S, 1, P(ws3), None))),
+                ("fp32 MFMA backward-data", lambda: _lib.check(L.ocrl_conv2d_bwd_data(P(x), P(w), P(act), P(y), B, S, S, 5, P(ws), None))),
+                ("3xbf16 split backward-data", lambda: _lib.check(L.ocrl_conv2d_bwd_data_x3(P(x), P(w), P(act), P(y), B, S, S, P(ws3), None)))):
+    ms = t(f)
+    print(f"{name:28s} B{B} {S}x{S}: {ms:.3f} ms (incl. the weight pack launch), {flop / ms / 1e9:.1f} TFLOP/s fp32-equivalent", flush=True)
