@@ -295,7 +295,12 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and reduce over gloo, to rehearse the N > 1 launch / barrier / reduction "
                          "plumbing on a one-GPU box (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
+    ap.add_argument("--conv-x3", action="store_true",
+                    help="EXPLORATORY, never the headline: the 5x5 / 64-channel forward and backward-data convolutions on the bf16 matrix pipe "
+                         "with fp32 operands split exactly into three bf16 numbers (csrc/conv_x3.hip); the line names the arithmetic in `dtype`")
     args = ap.parse_args()
+    if args.conv_x3:
+        os.environ["OCRL_CONV_X3"] = "1"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)      # plain `python bench.py --gpus N`: this process only spawns the ranks, it never touches a GPU
@@ -358,7 +363,8 @@ def main():
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(timed_region.median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if not args.conv_x3 else "f32 (exploratory: 5x5 conv fwd/bwd-data as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"{name} {S}x{S}, {K} slots, 3 iters" + (", vocab 4096, d_model 192, 4 decoder blocks" if args.workload == "slate" else
                                ", CNN encoder + slot attention + spatial-broadcast decoder") +
                                "; full update() step (fwd+bwd+all-reduce+inf-norm clip+Adam), train mode dropout 0.1, device RNG; "

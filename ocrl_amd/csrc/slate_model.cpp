@@ -133,6 +133,7 @@ float* SlateModel::carve(const char* name, size_t n) {
 void SlateModel::layout_workspace(bool commit) {
     ws_commit_ = commit;
     ws_off_ = 0;
+    x3_of_.clear();
     const size_t B = Bmax, BT = B * T, BN = B * N, BK = B * K;
     metrics_ = carve("metrics", 64);
     // transient scratch: split-k slabs (<= 1024 slabs of the largest weight tile set), wgrad slabs, column sums
@@ -175,6 +176,12 @@ void SlateModel::layout_workspace(bool commit) {
         const int cin = i == 0 ? 8 : 64;
         cw_fwd_[i] = carve(nullptr, (size_t)25 * cin * 64);
         cw_bwd_[i] = i == 0 ? nullptr : carve(nullptr, (size_t)25 * 64 * 64);
+        if (conv_x3_ < 0) { const char* e = getenv("OCRL_CONV_X3"); conv_x3_ = e ? atoi(e) : 0; }
+        if (conv_x3_ && i > 0) {          // exploratory split-precision packs beside the fp32 ones (csrc/conv_x3.hip)
+            float* f3 = carve(nullptr, conv_x3_pack_floats());
+            float* b3 = carve(nullptr, conv_x3_pack_floats());
+            if (ws_commit_) { x3_of_[cw_fwd_[i]] = f3; x3_of_[cw_bwd_[i]] = b3; }
+        }
     }
     gslots_ = carve(nullptr, BK * D); gslots0_ = carve(nullptr, BK * D);
     gA_ = carve(nullptr, BN * 64); gB_ = carve(nullptr, BN * 64); gC_ = cfg.use_bcdec ? gA_ : carve(nullptr, BN * 64);
@@ -418,6 +425,10 @@ int SlateModel::conv_layer_fwd(const float* x, const float* pack, const float* b
                                int relu, const float* posmap, const float* mask, hipStream_t st) {
     ConvArgs a;
     a.X = x; a.Wp = pack; a.Y = y; a.B = Bn; a.H = Hh; a.W = Ww; a.bias = bias; a.relu = relu; a.posmap = posmap; a.mask = mask;
+    if (conv_x3_ > 0 && KS == 5 && CIN == 64 && !conv_lowlat_) {
+        auto it = x3_of_.find(pack);
+        if (it != x3_of_.end()) return conv_x3_launch(a, it->second, st);
+    }
     return conv_fwd_launch(a, KS, CIN, 64, st, conv_lowlat_);
 }
 int SlateModel::conv_layer_wgrad(const float* x, const float* dy, float* dW, float* db, int Bn, int Hh, int Ww, int KS, int CIN,
@@ -435,6 +446,13 @@ int SlateModel::pack_weights(hipStream_t st, bool encoder_only) {
     RC(conv_pack_launch(P("_enc._encoder.1.m.weight"), cw_fwd_[1], cw_bwd_[1], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_enc._encoder.2.m.weight"), cw_fwd_[2], cw_bwd_[2], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_enc._encoder.3.weight"), cw_fwd_[3], cw_bwd_[3], 5, 64, 64, 64, st));
+    if (conv_x3_ > 0) {
+        const char* names[4] = {nullptr, "_enc._encoder.1.m.weight", "_enc._encoder.2.m.weight", "_enc._encoder.3.weight"};
+        for (int i = 1; i < 4; ++i) {
+            auto f = x3_of_.find(cw_fwd_[i]), b = x3_of_.find(cw_bwd_[i]);
+            if (f != x3_of_.end()) RC(conv_pack_x3_launch(P(names[i]), const_cast<float*>(f->second), b != x3_of_.end() ? const_cast<float*>(b->second) : nullptr, st));
+        }
+    }
     if (!cfg.use_bcdec && !encoder_only) {
         RC(conv_pack_launch(P("_dvae._decoder.1.m.weight"), dw_fwd_[0], dw_bwd_[0], 3, 64, 64, 64, st));
         RC(conv_pack_launch(P("_dvae._decoder.6.m.weight"), dw_fwd_[1], dw_bwd_[1], 3, 64, 64, 64, st));

@@ -146,6 +146,8 @@ private:
     PackEntry* sa_pack_dev_ = nullptr;
     int sa_pack_n_ = 0, sa_pack_max_ = 0;
     float *cw_fwd_[4], *cw_bwd_[4];       // CNN encoder conv packs
+    int conv_x3_ = -1;                    // OCRL_CONV_X3=1 (exploratory): the 5x5 / 64-channel layers on the split-precision bf16 kernel
+    std::map<const float*, const float*> x3_of_;      // fp32 pack -> its split-precision pack
     float *dw_fwd_[2], *dw_bwd_[2];       // dVAE decoder 3x3 conv packs
     float *w11p_;                         // [4,64] padded copy of the dVAE output conv
     float *mem_, *emb_;
