@@ -9,7 +9,8 @@
 //
 // Kernel shape: 8 rows x 32 pixels per workgroup, a wave owns two rows (two 32-pixel M blocks) x 64 output channels, so one weight
 // fragment feeds two MFMAs per product and the packed weights (three bf16 planes, [tap][chunk][n-block][plane][lane][8]) can stream
-// from L2 at 32 B/clk/CU.  The halo stays fp32 in LDS (12 x 36 pixels x 68 floats = 117.5 KB, one workgroup per CU) and an A
+// from L2 at 32 B/clk/CU.  The halo stays fp32 in LDS, 32 input channels at a time (two phases per tile, 62 KB, two workgroups per
+// CU; the first version held all 64 channels, 117.5 KB, one workgroup per CU: 2.05 ms per launch at B = 128 / 128x128), and an A
 // fragment (8 channels of a pixel) is split into its three bf16 planes in registers right before its MFMAs (bit masks, two exact
 // subtractions and three v_perm_b32 per pair of values, issued in the shadow of the MFMAs).  Same epilogue features as
 // conv_fwd_kernel (bias, ReLU / ELU, position map, activation mask), so it also serves the backward-data pass.
@@ -47,8 +48,12 @@ __device__ __forceinline__ void x3_split(const float4& a, const float4& b, uint4
 }
 #define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(256, 1) void conv_x3_kernel(ConvArgs p, const uint4* __restrict__ Wp3) {
-    constexpr int KS = X3_KS, P = KS / 2, HW_ = X3_HW, HH_ = X3_HH, LDH = X3_LDH, NCH = X3_NCH, CIN = 64, COUT = 64;
+// Two workgroups per CU: the input channels are processed in two phases of 32 (a 12 x 36 x 36-float halo = 62 KB per workgroup), so
+// one workgroup's halo loads and epilogue run under the other's MFMAs and every SIMD holds two waves.
+#define X3_CP 32          // input channels per phase
+#define X3_LDP 36         // floats per halo pixel of a phase (32 + 4: conflict-free ds_read_b128 over 16 pixels)
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs p, const uint4* __restrict__ Wp3) {
+    constexpr int KS = X3_KS, P = KS / 2, HW_ = X3_HW, HH_ = X3_HH, LDH = X3_LDP, NCL = X3_CP / 16, CIN = 64, COUT = 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_x = (p.W + X3_TW - 1) / X3_TW, tiles_y = (p.H + X3_TH - 1) / X3_TH;
     int bid = blockIdx.x;
@@ -60,30 +65,6 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(ConvArgs p, const uint4
     const int ty = bid % tiles_y; bid /= tiles_y;
     const int b = bid;
     const int x0 = tx * X3_TW, y0 = ty * X3_TH;
-    {   // halo tile -> LDS in three batches (loads of a batch issued before its stores)
-        constexpr int F4 = CIN / 4, TOTAL = HH_ * HW_ * F4, NB = 9, NBATCH = (TOTAL + 256 * NB - 1) / (256 * NB);
-        const float* Xb = p.X + (size_t)b * p.H * p.W * CIN;
-#pragma unroll 1
-        for (int bt = 0; bt < NBATCH; ++bt) {
-            float4 hv[NB];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int idx = threadIdx.x + (bt * NB + i) * 256;
-                const int c4 = idx % F4, hp = idx / F4;
-                const int hx = hp % HW_, hy = hp / HW_;
-                const int y = y0 - P + hy, x = x0 - P + hx;
-                hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < TOTAL && y >= 0 && y < p.H && x >= 0 && x < p.W) hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * p.W + x) * CIN + c4 * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int idx = threadIdx.x + (bt * NB + i) * 256;
-                if (idx < TOTAL) *reinterpret_cast<float4*>(smem + (idx / F4) * LDH + (idx % F4) * 4) = hv[i];
-            }
-        }
-    }
-    __syncthreads();
-
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
     f32x16 acc[2][2];
 #pragma unroll
@@ -92,84 +73,129 @@ __global__ __launch_bounds__(256, 1) void conv_x3_kernel(ConvArgs p, const uint4
         for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-    // operand rings of one tap (NCH slots): slot c holds the raw A values (two rows) and the six B fragments of chunk c; after its
-    // MFMAs are issued it is refilled with the next tap's chunk c, three chunks ahead of its use
-    const uint4* wl = Wp3 + lane;
-    float4 ra[NCH][2][2];
-    uint4 rb[NCH][2][3];
+    const float* Xb = p.X + (size_t)b * p.H * p.W * CIN;
     const float* abase = smem + ((2 * wave) * HW_ + li) * LDH + 8 * lh;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rb[c][n][pl] = wl[((c * 2 + n) * 3 + pl) * 64];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ra[c][m][0] = *reinterpret_cast<const float4*>(abase + m * HW_ * LDH + c * 16);
-            ra[c][m][1] = *reinterpret_cast<const float4*>(abase + m * HW_ * LDH + c * 16 + 4);
-        }
-    }
+
 #pragma unroll 1
-    for (int tap = 0; tap < KS * KS; ++tap) {
-        const int tn = tap + 1;
-        const bool more = tn < KS * KS;
-        const int ky = more ? tn / KS : 0, kx = more ? tn - (tn / KS) * KS : 0;
-        const float* an = abase + (ky * HW_ + kx) * LDH;
-        const uint4* wn = wl + (size_t)(more ? tn : 0) * NCH * 2 * 3 * 64;
+    for (int ph = 0; ph < CIN / X3_CP; ++ph) {
+        if (ph) __syncthreads();            // every wave has left the previous phase's halo
+        {   // this phase's 32 channels of the halo -> LDS, two batches (loads of a batch issued before its stores)
+            constexpr int F4 = X3_CP / 4, TOTAL = HH_ * HW_ * F4, NB = 7, NBATCH = (TOTAL + 256 * NB - 1) / (256 * NB);
+#pragma unroll 1
+            for (int bt = 0; bt < NBATCH; ++bt) {
+                float4 hv[NB];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            uint4 ah[2], am[2], al[2];
+                for (int i = 0; i < NB; ++i) {
+                    const int idx = threadIdx.x + (bt * NB + i) * 256;
+                    const int c4 = idx % F4, hp = idx / F4;
+                    const int hx = hp % HW_, hy = hp / HW_;
+                    const int y = y0 - P + hy, x = x0 - P + hx;
+                    hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (idx < TOTAL && y >= 0 && y < p.H && x >= 0 && x < p.W)
+                        hv[i] = *reinterpret_cast<const float4*>(Xb + ((size_t)y * p.W + x) * CIN + ph * X3_CP + c4 * 4);
+                }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) x3_split(ra[c][m][0], ra[c][m][1], ah[m], am[m], al[m]);
-            uint4 bh[2], bm[2], bl[2];
+                for (int i = 0; i < NB; ++i) {
+                    const int idx = threadIdx.x + (bt * NB + i) * 256;
+                    if (idx < TOTAL) *reinterpret_cast<float4*>(smem + (idx / F4) * LDH + (idx % F4) * 4) = hv[i];
+                }
+            }
+        }
+        __syncthreads();
+        // Operand rings of one tap (NCL slots): slot c holds the raw A values (two rows) and the six B fragments of the phase's chunk c.
+        // A tap is NCL regions, one per chunk, fenced by sched_barriers so the compiler keeps this order (left alone it sinks every load to
+        // the top of the next tap and the MFMAs wait for them).  Region c: (1) refill slot c's B fragments with the NEXT tap's chunk c;
+        // (2) the 24 MFMAs of chunk c on the A planes that were split one region earlier; (3) split the raw A values of the next chunk
+        // into their planes (VALU work in the shadow of (2)); (4) refill that slot's raw A values from LDS.
+        const uint4* wl = Wp3 + (size_t)(ph * NCL) * 2 * 3 * 64 + lane;          // chunk index inside a tap: ph * NCL + c
+        float4 ra[NCL][2][2];
+        uint4 rb[NCL][2][3];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) { bh[n] = rb[c][n][0]; bm[n] = rb[c][n][1]; bl[n] = rb[c][n][2]; }
-            // refill the slot (after the last tap this harmlessly re-reads tap 0: no branch in the loop body)
+        for (int c = 0; c < NCL; ++c) {
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) rb[c][n][pl] = wn[((c * 2 + n) * 3 + pl) * 64];
+                for (int pl = 0; pl < 3; ++pl) rb[c][n][pl] = wl[((c * 2 + n) * 3 + pl) * 64];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                ra[c][m][0] = *reinterpret_cast<const float4*>(an + m * HW_ * LDH + c * 16);
-                ra[c][m][1] = *reinterpret_cast<const float4*>(an + m * HW_ * LDH + c * 16 + 4);
+                ra[c][m][0] = *reinterpret_cast<const float4*>(abase + m * HW_ * LDH + c * 16);
+                ra[c][m][1] = *reinterpret_cast<const float4*>(abase + m * HW_ * LDH + c * 16 + 4);
             }
+        }
+        uint4 ah[2], am[2], al[2];           // planes of the chunk whose MFMAs come next
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) x3_split(ra[0][m][0], ra[0][m][1], ah[m], am[m], al[m]);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    f32x16 a_ = acc[m][n];
-                    a_ = X3_MFMA(al[m], bh[n], a_);          // small terms first
-                    a_ = X3_MFMA(ah[m], bl[n], a_);
-                    a_ = X3_MFMA(am[m], bm[n], a_);
-                    a_ = X3_MFMA(am[m], bh[n], a_);
-                    a_ = X3_MFMA(ah[m], bm[n], a_);
-                    a_ = X3_MFMA(ah[m], bh[n], a_);
-                    acc[m][n] = a_;
+        for (int m = 0; m < 2; ++m) {        // slot 0's raw values are consumed: refill it with tap 1's chunk 0 (the last region of tap 0 splits it)
+            ra[0][m][0] = *reinterpret_cast<const float4*>(abase + 1 * LDH + m * HW_ * LDH);
+            ra[0][m][1] = *reinterpret_cast<const float4*>(abase + 1 * LDH + m * HW_ * LDH + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            // next tap (B refills, A refills of the chunks > 0) and the tap after it (A refill of chunk 0, whose split runs one region early)
+            const int tn = tap + 1 < KS * KS ? tap + 1 : 0, t2 = tap + 2 < KS * KS ? tap + 2 : 0;
+            const float* an = abase + ((tn / KS) * HW_ + tn % KS) * LDH;
+            const float* an2 = abase + ((t2 / KS) * HW_ + t2 % KS) * LDH;
+            const uint4* wn = wl + (size_t)tn * X3_NCH * 2 * 3 * 64;
+#pragma unroll
+            for (int c = 0; c < NCL; ++c) {
+                uint4 bh[2], bm[2], bl[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) { bh[n] = rb[c][n][0]; bm[n] = rb[c][n][1]; bl[n] = rb[c][n][2]; }
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) rb[c][n][pl] = wn[((c * 2 + n) * 3 + pl) * 64];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        f32x16 a_ = acc[m][n];
+                        a_ = X3_MFMA(al[m], bh[n], a_);          // small terms first
+                        a_ = X3_MFMA(ah[m], bl[n], a_);
+                        a_ = X3_MFMA(am[m], bm[n], a_);
+                        a_ = X3_MFMA(am[m], bh[n], a_);
+                        a_ = X3_MFMA(ah[m], bm[n], a_);
+                        a_ = X3_MFMA(ah[m], bh[n], a_);
+                        acc[m][n] = a_;
+                    }
+                const int cn = (c + 1) & (NCL - 1);
+                uint4 nh[2], nm[2], nl[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) x3_split(ra[cn][m][0], ra[cn][m][1], nh[m], nm[m], nl[m]);
+                {   // slot cn's raw values are consumed: refill it -- chunk cn of the next tap; for cn = 0 of the tap after the next, because
+                    // slot 0 already holds the next tap's chunk 0 when the last region splits it
+                    const float* src = (cn == 0 ? an2 : an) + cn * 16;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        ra[cn][m][0] = *reinterpret_cast<const float4*>(src + m * HW_ * LDH);
+                        ra[cn][m][1] = *reinterpret_cast<const float4*>(src + m * HW_ * LDH + 4);
+                    }
                 }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) { ah[m] = nh[m]; am[m] = nm[m]; al[m] = nl[m]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
-    // ---- epilogue (conv_fwd_kernel's): each (wave, row) tile of 32 pixels x 64 channels through an LDS patch, float4 rows out
+    // ---- epilogue (conv_fwd_kernel's), one of the wave's two rows at a time: a 32-pixel x 64-channel tile through the wave's LDS
+    // patch, float4 rows out
     __syncthreads();
+    const int c4 = lane & 15, px0 = lane >> 4;
+    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* patch = smem + wave * 32 * (COUT + 4);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        float* patch = smem + (wave * 2 + m) * 32 * (COUT + 4);
+        if (m) __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * (COUT + 4) + tn * 32 + li] = acc[m][tn][r];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int c4 = lane & 15, px0 = lane >> 4;
-    const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
+        __builtin_amdgcn_wave_barrier();
         const int y = y0 + 2 * wave + m;
         if (y >= p.H) continue;
-        const float* patch = smem + (wave * 2 + m) * 32 * (COUT + 4);
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int px = ps * 4 + px0, x = x0 + px;
@@ -230,8 +256,8 @@ int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st
 int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st) {
     OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && pack3, "conv x3: empty input / missing pack");
     OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)pack3 & 15) == 0, "conv x3: X / pack must be 16-byte aligned");
-    constexpr int smem = X3_HH * X3_HW * X3_LDH * 4;
-    static_assert(X3_HH * X3_HW * X3_LDH >= 8 * 32 * 68, "the halo region must hold the eight epilogue patches");
+    constexpr int smem = X3_HH * X3_HW * X3_LDP * 4;
+    static_assert(X3_HH * X3_HW * X3_LDP >= 4 * 32 * 68, "the halo region must hold the four epilogue patches");
     static bool attr_set = false;
     if (!attr_set) {
         OCRL_HIP(hipFuncSetAttribute((const void*)conv_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));

@@ -7,6 +7,8 @@ from ocrl_amd import _lib
 L = _lib.lib(); P = _lib.ptr
 B, S = int(os.environ.get("B", 128)), int(os.environ.get("S", 128))
 x = torch.randn(B, S, S, 64, device="cuda"); w = torch.randn(64, 64, 5, 5, device="cuda") / 40; b = torch.randn(64, device="cuda")
+if os.environ.get("ZERO"):          # DVFS check: the same instruction stream on zeros draws less power and holds a higher clock
+    x.zero_(); w.zero_()
 y = torch.empty_like(x); act = torch.randn_like(x)
 ws3 = torch.empty(L.ocrl_conv2d_x3_ws_floats(), device="cuda"); ws = torch.empty(2 * 25 * 64 * 64, device="cuda")
 flop = 2.0 * 25 * 64 * 64 * B * S * S
