@@ -127,6 +127,8 @@ int ocrl_conv2d_fwd_lowlat(const float* x, const float* w, const float* bias, fl
 size_t ocrl_conv2d_x3_ws_floats(void);
 int ocrl_conv2d_fwd_x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int relu, float* ws, void* stream);
 int ocrl_conv2d_bwd_data_x3(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, float* ws, void* stream);
+/* its weight gradient [64,64,5,5]; ws from ocrl_conv2d_wgrad_ws_floats(B, H, W, 5, 64) */
+int ocrl_conv2d_bwd_weight_x3(const float* x, const float* dy, float* dw, int B, int H, int W, float* ws, size_t ws_floats, void* stream);
 /* grad wrt input of the same conv (square 64->64 layers): dx = conv_transpose(dy, w) * (mask > 0 if mask). ws: 2*ks*ks*64*64 floats. */
 int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream);
 /* grad wrt weight (reference layout [64,cin,ks,ks]) and bias [64] (may be NULL); ws from ocrl_conv2d_wgrad_ws_floats. */

@@ -174,9 +174,15 @@ int ocrl_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db
     if (ws_floats < ocrl_conv2d_wgrad_ws_floats(B, H, W, ks, cin_pad)) { ocrl_set_error("ocrl_conv2d_bwd_weight: workspace too small"); return 1; }
     WgradArgs a;
     a.X = x; a.dY = dy; a.part = ws; a.B = B; a.H = H; a.W = W;
-    if (conv_wgrad_launch(a, ks, cin_pad, 64, cin, dw, 0, ST(stream))) return 1;
+    if (conv_wgrad_launch(a, ks, cin_pad, 64, cin, dw, 0, ST(stream), 0)) return 1;
     if (db) return colsum_launch(dy, 64, db, (long long)B * H * W, 64, 0, 1.f, ws, ws_floats, ST(stream));
     return 0;
+}
+int ocrl_conv2d_bwd_weight_x3(const float* x, const float* dy, float* dw, int B, int H, int W, float* ws, size_t ws_floats, void* stream) {
+    if (ws_floats < ocrl_conv2d_wgrad_ws_floats(B, H, W, 5, 64)) { ocrl_set_error("ocrl_conv2d_bwd_weight_x3: workspace too small"); return 1; }
+    WgradArgs a;
+    a.X = x; a.dY = dy; a.part = ws; a.B = B; a.H = H; a.W = W;
+    return conv_wgrad_launch(a, 5, 64, 64, 64, dw, 0, ST(stream), 1);
 }
 int ocrl_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, long long R, int F, void* stream) {
     return layernorm_fwd_launch(x, g, b, y, mean, rstd, R, F, ST(stream));

@@ -512,11 +512,15 @@ size_t conv_wgrad_ws_floats(int B, int H, int W, int KS, int CIN) {
     return (size_t)conv_wgrad_chunks(B, H, W, KS) * ks * KS * KS * 64 * CIN;
 }
 
-int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st) {
+int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st, int x3) {
     OCRL_REQUIRE(COUT == 64, "conv wgrad: COUT must be 64 (got %d)", COUT);
     const int nchunk = conv_wgrad_chunks(a.B, a.H, a.W, KS);
+    static int x3_env = -1;
+    if (x3_env < 0) { const char* e = getenv("OCRL_CONV_X3"); x3_env = e ? atoi(e) : 0; }
+    if (x3 < 0) x3 = x3_env;
     int rc;
-    if (KS == 5 && CIN == 64) rc = conv_wgrad_cfg<5, 64>(a, nchunk, st);
+    if (KS == 5 && CIN == 64 && x3 > 0) rc = conv_wgrad_x3_stage(a, nchunk, st);
+    else if (KS == 5 && CIN == 64) rc = conv_wgrad_cfg<5, 64>(a, nchunk, st);
     else if (KS == 5 && CIN == 8) rc = conv_wgrad_cfg<5, 8>(a, nchunk, st);
     else if (KS == 3 && CIN == 64) rc = conv_wgrad_cfg<3, 64>(a, nchunk, st);
     else { ocrl_set_error("conv wgrad: unsupported KS=%d CIN=%d", KS, CIN); return 1; }

@@ -247,6 +247,159 @@ __global__ void conv_pack_x3_kernel(const float* __restrict__ W, uint4* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the same layer on the split-precision path: dW[tap][co][ci] = sum_pixels dY[p][co] * X[p + tap][ci], pixels are
+// the MFMA k dimension (16 per v_mfma_f32_32x32x16_bf16).  Same decomposition as conv_wgrad_kernel (conv.hip): grid = (chunks, KS), a
+// workgroup owns kernel row ky and walks 4 x 32-pixel tiles, a wave owns one 32 x 32 quadrant of [co x ci] for the five kx, partial
+// slabs [slab][ky*5+kx][co][ci] go to conv_wgrad_reduce_kernel.  A bf16 MFMA wants its 8 k-values per lane contiguous, i.e. 8
+// consecutive PIXELS of one channel, so the tiles are stored transposed in LDS ([channel][pixel], fp32) and a fragment is two
+// (dY) or three (X: the 12 pixels that cover the five kx windows) ds_read_b128; the values are split into their three bf16 planes in
+// registers, the X planes packed once for even and once for odd kx (the windows of neighbouring kx overlap by 7 pixels).
+#define WX_TH 4
+#define WX_TW 32
+#define WX_HW (WX_TW + X3_KS - 1)
+#define WX_LDY (WX_TH * WX_TW + 4)        // floats per co row of the transposed dY tile
+#define WX_LDX (WX_TH * WX_HW + 4)        // floats per ci row of the transposed X tile
+__device__ __forceinline__ void x3_planes(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = x3_hi(v);
+    const float r = v - __builtin_bit_cast(float, h);
+    m = x3_hi(r);
+    l = __builtin_bit_cast(uint32_t, r - __builtin_bit_cast(float, m));
+}
+#define X3_PK(hi_, lo_) __builtin_amdgcn_perm((hi_), (lo_), 0x07060302u)
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
+    constexpr int KS = X3_KS, P = KS / 2, HW_ = WX_HW, CIN = 64, COUT = 64, TH_ = WX_TH, TW_ = WX_TW, LDY = WX_LDY, LDX = WX_LDX;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dYt = smem;                    // [COUT][LDY]: dY tile, pixel index = row * 32 + x
+    float* Xt = smem + COUT * LDY;        // [CIN][LDX]: X tile rows shifted by ky, pixel index = row * 36 + hx
+    int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    {   // the KS workgroups that stream the same pixel tiles for different kernel rows sit on one XCD (conv_wgrad_kernel)
+        const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, x = lin & 7, y = lin >> 3;
+        lin = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int cx = lin / (int)gridDim.y, ky = lin % (int)gridDim.y;
+    const int tiles_x = (p.W + TW_ - 1) / TW_, tiles_y = (p.H + TH_ - 1) / TH_;
+    const int ntiles = tiles_x * tiles_y * p.B;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int coh = wave >> 1, cih = wave & 1;
+    f32x16 acc[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    constexpr int FY = COUT / 4, FX = CIN / 4;
+    constexpr int NDY = (TH_ * TW_ * FY + 255) / 256, XT = TH_ * HW_ * FX, NX = (XT + 255) / 256;
+    float4 rdy[NDY], rx[NX];
+    auto gload = [&](int t) {
+        int q = t;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y; q /= tiles_y;
+        const int b = q;
+        const int x0 = tx * TW_, y0 = ty * TH_;
+        const float* gy = p.dY + (size_t)b * p.H * p.W * COUT;
+        const float* gx = p.X + (size_t)b * p.H * p.W * CIN;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int c4 = idx % FY, pp = idx / FY;
+            const int x = x0 + (pp % TW_), y = y0 + (pp / TW_);
+            rdy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < p.H && x < p.W) rdy[i] = *reinterpret_cast<const float4*>(gy + ((size_t)y * p.W + x) * COUT + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int c4 = idx % FX, hp = idx / FX;
+            const int x = x0 - P + (hp % HW_), y = y0 + ky - P + (hp / HW_);
+            rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < XT && y >= 0 && y < p.H && x >= 0 && x < p.W) rx[i] = *reinterpret_cast<const float4*>(gx + ((size_t)y * p.W + x) * CIN + c4 * 4);
+        }
+    };
+    const float* arow = dYt + (coh * 32 + li) * LDY + 8 * lh;
+    const float* brow = Xt + (cih * 32 + li) * LDX + 8 * lh;
+    if ((int)cx < ntiles) gload(cx);
+    for (int t = cx; t < ntiles; t += gridDim.x) {
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {          // transposed stores: [channel][pixel]
+            const int idx = threadIdx.x + i * 256, c = (idx % FY) * 4, pp = idx / FY;
+            dYt[(c + 0) * LDY + pp] = rdy[i].x; dYt[(c + 1) * LDY + pp] = rdy[i].y; dYt[(c + 2) * LDY + pp] = rdy[i].z; dYt[(c + 3) * LDY + pp] = rdy[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = threadIdx.x + i * 256, c = (idx % FX) * 4, hp = idx / FX;
+            if (idx < XT) { Xt[(c + 0) * LDX + hp] = rx[i].x; Xt[(c + 1) * LDX + hp] = rx[i].y; Xt[(c + 2) * LDX + hp] = rx[i].z; Xt[(c + 3) * LDX + hp] = rx[i].w; }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);
+        float4 na[2], nb[3];                  // raw values of the next (row, 16-pixel group)
+        na[0] = *reinterpret_cast<const float4*>(arow); na[1] = *reinterpret_cast<const float4*>(arow + 4);
+        nb[0] = *reinterpret_cast<const float4*>(brow); nb[1] = *reinterpret_cast<const float4*>(brow + 4); nb[2] = *reinterpret_cast<const float4*>(brow + 8);
+#pragma unroll
+        for (int it = 0; it < TH_ * 2; ++it) {
+            // ---- planes of this group: dY (8 pixels of channel co) and X (12 pixels of channel ci)
+            uint4 ah, am, al;
+            x3_split(na[0], na[1], ah, am, al);
+            const float v[12] = {nb[0].x, nb[0].y, nb[0].z, nb[0].w, nb[1].x, nb[1].y, nb[1].z, nb[1].w, nb[2].x, nb[2].y, nb[2].z, nb[2].w};
+            uint32_t vh[12], vm[12], vl[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) x3_planes(v[k], vh[k], vm[k], vl[k]);
+            uint32_t eh[6], em[6], el[6], oh[5], om[5], ol[5];       // pairs (2i, 2i+1) and (2i+1, 2i+2)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { eh[i] = X3_PK(vh[2 * i + 1], vh[2 * i]); em[i] = X3_PK(vm[2 * i + 1], vm[2 * i]); el[i] = X3_PK(vl[2 * i + 1], vl[2 * i]); }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { oh[i] = X3_PK(vh[2 * i + 2], vh[2 * i + 1]); om[i] = X3_PK(vm[2 * i + 2], vm[2 * i + 1]); ol[i] = X3_PK(vl[2 * i + 2], vl[2 * i + 1]); }
+            // ---- raw values of the next group
+            if (it + 1 < TH_ * 2) {
+                const int rr = (it + 1) >> 1, g = (it + 1) & 1;
+                const float* an = arow + rr * TW_ + g * 16;
+                const float* bn = brow + rr * HW_ + g * 16;
+                na[0] = *reinterpret_cast<const float4*>(an); na[1] = *reinterpret_cast<const float4*>(an + 4);
+                nb[0] = *reinterpret_cast<const float4*>(bn); nb[1] = *reinterpret_cast<const float4*>(bn + 4); nb[2] = *reinterpret_cast<const float4*>(bn + 8);
+            }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int o = kx >> 1;
+                const uint4 bh = (kx & 1) ? make_uint4(oh[o], oh[o + 1], oh[o + 2], oh[o + 3]) : make_uint4(eh[o], eh[o + 1], eh[o + 2], eh[o + 3]);
+                const uint4 bm = (kx & 1) ? make_uint4(om[o], om[o + 1], om[o + 2], om[o + 3]) : make_uint4(em[o], em[o + 1], em[o + 2], em[o + 3]);
+                const uint4 bl = (kx & 1) ? make_uint4(ol[o], ol[o + 1], ol[o + 2], ol[o + 3]) : make_uint4(el[o], el[o + 1], el[o + 2], el[o + 3]);
+                f32x16 a_ = acc[kx];
+                a_ = X3_MFMA(al, bh, a_);
+                a_ = X3_MFMA(ah, bl, a_);
+                a_ = X3_MFMA(am, bm, a_);
+                a_ = X3_MFMA(am, bh, a_);
+                a_ = X3_MFMA(ah, bm, a_);
+                a_ = X3_MFMA(ah, bh, a_);
+                acc[kx] = a_;
+            }
+        }
+    }
+    // ---- partial slab [slab][ky*KS+kx][co][CIN] (conv_wgrad_kernel's layout: conv_wgrad_reduce_kernel sums the slabs)
+    float* out = p.part + ((size_t)cx * KS * KS + ky * KS) * COUT * CIN;
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[((size_t)kx * COUT + co) * CIN + cih * 32 + li] = acc[kx][r];
+        }
+}
+int conv_wgrad_x3_stage(const WgradArgs& a, int nchunk, hipStream_t st) {
+    constexpr int smem = (64 * WX_LDY + 64 * WX_LDX) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OCRL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int pi = prof_begin(PROF_WGRAD, st);
+    hipLaunchKernelGGL(conv_wgrad_x3_kernel, dim3(nchunk, X3_KS), dim3(256), smem, st, a);
+    prof_end(pi, st);
+    OCRL_CHECK_LAUNCH("conv_wgrad_x3_kernel");
+    return 0;
+}
+
 size_t conv_x3_pack_floats() { return (size_t)25 * 4 * 2 * 3 * 64 * 4; }      // floats per pack (614 KB)
 int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st) {
     hipLaunchKernelGGL(conv_pack_x3_kernel, dim3(cdiv(25 * 4 * 2 * 64, 256)), dim3(256), 0, st, W, reinterpret_cast<uint4*>(fwd3), reinterpret_cast<uint4*>(bwd3));

@@ -82,6 +82,8 @@ struct ConvArgs {
 size_t conv_x3_pack_floats();
 int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st);          // W [64][64][5][5]; bwd3 may be null
 int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st);
+struct WgradArgs;
+int conv_wgrad_x3_stage(const WgradArgs& a, int nchunk, hipStream_t st);       // first stage of conv_wgrad_launch (same partial slabs)
 struct WgradArgs {
     const float* X = nullptr;       // [B,H,W,CIN]
     const float* dY = nullptr;      // [B,H,W,COUT]
@@ -91,7 +93,8 @@ struct WgradArgs {
 // low_latency: the caller's grid is small (inference at a few images): 5x5 / 64-channel forward layers whose throughput grid would leave
 // most CUs idle go to the k-split kernel (conv_lat_kernel); results differ from the throughput kernel by fp32 summation order
 int conv_fwd_launch(const ConvArgs& a, int KS, int CIN, int COUT, hipStream_t st, int low_latency = 0);
-int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st);
+// x3: 1 = the split-precision first stage for the 5x5 / 64-channel layer (exploratory), 0 = fp32 MFMA, -1 = by OCRL_CONV_X3
+int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_real, float* dW, int accumulate, hipStream_t st, int x3 = -1);
 size_t conv_wgrad_ws_floats(int B, int H, int W, int KS, int CIN);
 int conv_pack_launch(const float* W, float* fwd, float* bwd, int KS, int CIN, int COUT, int cin_real, hipStream_t st);
 

@@ -162,9 +162,20 @@ def test_conv_split_precision_exploratory(L, B, H, W):
     L.check(L.lib().ocrl_conv2d_bwd_data(P(dyd), P(wd), P(actd), P(dx0), B, H, W, 5, P(ws0), None))
     torch.cuda.synchronize()
     eb, eb0 = relerr(dx.cpu().permute(0, 3, 1, 2), refb), relerr(dx0.cpu().permute(0, 3, 1, 2), refb)
-    log(f"conv 5x5 split-precision (3 x bf16, 6 products) B{B} {H}x{W}: forward {e:.2e} (fp32 MFMA kernel {e0:.2e}), backward-data {eb:.2e} ({eb0:.2e}) vs fp64")
-    assert torch.isfinite(y).all() and torch.isfinite(dx).all()
-    assert e < TOL and eb < TOL
+    # weight gradient
+    wg = torch.zeros(64, 64, 5, 5, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), wg, None, padding=2).backward(dy.double())
+    n = L.lib().ocrl_conv2d_wgrad_ws_floats(B, H, W, 5, 64)
+    wsw = torch.empty(n, device="cuda")
+    dw, dw0 = torch.full((64, 64, 5, 5), float("nan"), device="cuda"), torch.empty(64, 64, 5, 5, device="cuda")
+    L.check(L.lib().ocrl_conv2d_bwd_weight_x3(P(xd), P(dyd), P(dw), B, H, W, P(wsw), n, None))
+    L.check(L.lib().ocrl_conv2d_bwd_weight(P(xd), P(dyd), P(dw0), None, B, H, W, 64, 64, 5, P(wsw), n, None))
+    torch.cuda.synchronize()
+    ew, ew0 = relerr(dw.cpu(), wg.grad), relerr(dw0.cpu(), wg.grad)
+    log(f"conv 5x5 split-precision (3 x bf16, 6 products) B{B} {H}x{W}: forward {e:.2e} (fp32 MFMA kernel {e0:.2e}), backward-data {eb:.2e} ({eb0:.2e}), "
+        f"weight gradient {ew:.2e} ({ew0:.2e}) vs fp64")
+    assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    assert e < TOL and eb < TOL and ew < TOL
 
 
 @pytest.mark.parametrize("B,S,ks", [(2, 16, 5), (2, 32, 5), (2, 12, 3)])

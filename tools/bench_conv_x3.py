@@ -11,6 +11,7 @@ if os.environ.get("ZERO"):          # DVFS check: the same instruction stream on
     x.zero_(); w.zero_()
 y = torch.empty_like(x); act = torch.randn_like(x)
 ws3 = torch.empty(L.ocrl_conv2d_x3_ws_floats(), device="cuda"); ws = torch.empty(2 * 25 * 64 * 64, device="cuda")
+nw = L.ocrl_conv2d_wgrad_ws_floats(B, S, S, 5, 64); wsw = torch.empty(nw, device="cuda"); dw = torch.empty(64, 64, 5, 5, device="cuda")
 flop = 2.0 * 25 * 64 * 64 * B * S * S
 def t(f, n=10):
     for _ in range(3): f()
@@ -23,6 +24,8 @@ def t(f, n=10):
 for name, f in (("fp32 MFMA forward", lambda: _lib.check(L.ocrl_conv2d_fwd(P(x), P(w), P(b), P(y), B, S, S, 64, 64, 5, 1, P(ws), None))),
                 ("3xbf16 split forward", lambda: _lib.check(L.ocrl_conv2d_fwd_x3(P(x), P(w), P(b), P(y), B, S, S, 1, P(ws3), None))),
                 ("fp32 MFMA backward-data", lambda: _lib.check(L.ocrl_conv2d_bwd_data(P(x), P(w), P(act), P(y), B, S, S, 5, P(ws), None))),
-                ("3xbf16 split backward-data", lambda: _lib.check(L.ocrl_conv2d_bwd_data_x3(P(x), P(w), P(act), P(y), B, S, S, P(ws3), None)))):
+                ("3xbf16 split backward-data", lambda: _lib.check(L.ocrl_conv2d_bwd_data_x3(P(x), P(w), P(act), P(y), B, S, S, P(ws3), None))),
+                ("fp32 MFMA weight gradient", lambda: _lib.check(L.ocrl_conv2d_bwd_weight(P(x), P(act), P(dw), None, B, S, S, 64, 64, 5, P(wsw), nw, None))),
+                ("3xbf16 split weight gradient", lambda: _lib.check(L.ocrl_conv2d_bwd_weight_x3(P(x), P(act), P(dw), B, S, S, P(wsw), nw, None)))):
     ms = t(f)
     print(f"{name:28s} B{B} {S}x{S}: {ms:.3f} ms (incl. the weight pack launch), {flop / ms / 1e9:.1f} TFLOP/s fp32-equivalent", flush=True)
