@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and reduce over gloo, to rehearse the N > 1 launch / barrier / reduction "
                          "plumbing on a one-GPU box (RCCL refuses two ranks on one device); the line is marked and is not a measurement")
+    ap.add_argument("--no-exploratory", action="store_true", help="skip the exploratory split-precision second pass of the default run")
     ap.add_argument("--conv-x3", action="store_true",
                     help="EXPLORATORY, never the headline: the 5x5 / 64-channel forward and backward-data convolutions on the bf16 matrix pipe "
                          "with fp32 operands split exactly into three bf16 numbers (csrc/conv_x3.hip); the line names the arithmetic in `dtype`")
@@ -363,7 +364,7 @@ def main():
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(timed_region.median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if not args.conv_x3 else "f32 (exploratory: 5x5 conv fwd/bwd-data as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate)",
+        "dtype": "f32" if not args.conv_x3 else "f32 (exploratory: 5x5 conv fwd/bwd-data/wgrad as 6 bf16 MFMA products of exact 3-way bf16 splits, fp32 accumulate)",
         "data": "synthetic",
         "config": {"workload": f"{name} {S}x{S}, {K} slots, 3 iters" + (", vocab 4096, d_model 192, 4 decoder blocks" if args.workload == "slate" else
                                ", CNN encoder + slot attention + spatial-broadcast decoder") +
@@ -395,6 +396,30 @@ def main():
                                  "note": "algorithmic bytes of the folded-projection form (12.6 MB/img forward, 33.5 MB/img backward at N=16384; the reference's "
                                          "materialised k|v form would move 75.5 MB/img forward); fwd / bwd = the chain on its own at the same shape, HIP events "
                                          "around its launches; pmc = matrix-pipe busy fraction / resident waves per SIMD / HBM bytes per launch from rocprofv3 counters"}
+    if world == 1 and args.workload == "slate" and not args.conv_x3 and not args.no_exploratory:
+        # EXPLORATORY second pass, never `value`: the same step with the 5x5 / 64-channel convolutions (forward, backward-data, weight
+        # gradient) on the bf16 matrix pipe, every fp32 operand split exactly into three bf16 numbers and six products accumulated in fp32
+        # (csrc/conv_x3.hip).  The GPU parity suite passes unchanged with OCRL_CONV_X3=1 (profiles/r03_exploratory_conv_x3_gpu_suite.log).
+        del model
+        torch.cuda.empty_cache()
+        os.environ["OCRL_CONV_X3"] = "1"
+        try:
+            torch.manual_seed(0)
+            model = ocrs.SLATE(ocr, env)
+            model._module._max_batch = B
+            model.to(dev)
+            model.train()
+            model._module.set_seed(1 + rank)
+            xa = argparse.Namespace(**{**vars(args), "steps": min(args.steps, 10), "warmup": min(args.warmup, 3)})
+            dtx, _, _, mx = timed_region(xa, dev, None, lambda i: model.update(obs_from_uint8(pool[i % len(pool)]), None, i), 0)
+            out["exploratory_conv_x3"] = {
+                "value": round(B * xa.steps / dtx, 2), "unit": "images/sec", "ms_per_step": round(dtx / xa.steps * 1e3, 3), "steps": xa.steps,
+                "arithmetic": "5x5 conv fwd / bwd-data / wgrad as 6 v_mfma_f32_32x32x16_bf16 products of exact 3-way bf16 splits of the fp32 operands, "
+                              "fp32 accumulate; everything else as the headline (fp32 MFMA)",
+                "final_loss": float(mx["loss"].item()),
+                "note": "not the graded number: opt-in (OCRL_CONV_X3=1 / --conv-x3); parity suite green with it enabled"}
+        finally:
+            os.environ.pop("OCRL_CONV_X3", None)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(S, 8, 3, use_bcdec=bool(ocr.use_bcdec), num_slots=int(ocr.slotattr.num_slots))
     if args.rehearse_on_one_gpu:

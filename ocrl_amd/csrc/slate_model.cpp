@@ -436,7 +436,7 @@ int SlateModel::conv_layer_wgrad(const float* x, const float* dy, float* dW, flo
     WgradArgs a;
     a.X = x; a.dY = dy; a.part = scratch_; a.B = Bn; a.H = Hh; a.W = Ww;
     OCRL_REQUIRE(conv_wgrad_ws_floats(Bn, Hh, Ww, KS, CIN) <= scratch_floats_, "conv wgrad: scratch too small");
-    RC(conv_wgrad_launch(a, KS, CIN, 64, cin_real, dW, 0, st));
+    RC(conv_wgrad_launch(a, KS, CIN, 64, cin_real, dW, 0, st, conv_x3_ > 0 ? 1 : 0));
     if (db) RC(colsum_launch(dy, 64, db, (long long)Bn * Hh * Ww, 64, 0, 1.f, scratch_, scratch_floats_, st));
     return 0;
 }

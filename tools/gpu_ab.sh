@@ -4,7 +4,7 @@ TAG=$1; shift
 mkdir -p gpurun_out
 for kv in "$@"; do
   name=$(echo "$kv" | tr ' =' '__')
-  env $kv timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_${name}.json 2> gpurun_out/${TAG}_${name}.err; rc=$?
+  env $kv timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exploratory > gpurun_out/${TAG}_${name}.json 2> gpurun_out/${TAG}_${name}.err; rc=$?
   if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then echo "[ab] $kv killed rc=$rc"; exit $rc; fi
   python - <<PY
 import json

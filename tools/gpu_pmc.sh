@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for pass in "f FETCH_SIZE" "w WRITE_SIZE" "o SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   set -- $pass; name=$1; shift
-  timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o $name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$name -o $name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-exploratory > $R/gpurun_out/pmc_$name.log 2>&1
   rc=$?; echo "[pmc] pass $name rc=$rc"
   if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then exit $rc; fi
 done

@@ -6,7 +6,7 @@ TAG=${1:-ser}; R=$PWD
 mkdir -p gpurun_out
 export OCRL_OVERLAP=0 OCRL_DW_SIDE=0
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1; rc=$?; echo "[serial] profile rc=$rc"
+timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-exploratory > $R/gpurun_out/${TAG}_prof.log 2>&1; rc=$?; echo "[serial] profile rc=$rc"
 if [ "$rc" != 0 ]; then tail -5 $R/gpurun_out/${TAG}_prof.log; exit $rc; fi
 cd $R
 DB=$(find gpurun_out/${TAG}_prof -name "*.db" | head -1)

@@ -22,7 +22,7 @@ except Exception as e:
     print("[session] bench line unreadable:", e)
 PY
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_prof.log 2>&1; rc=$?; echo "[session] profile rc=$rc"; guard $rc
+timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_prof -o ${TAG} -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exploratory > $R/gpurun_out/${TAG}_prof.log 2>&1; rc=$?; echo "[session] profile rc=$rc"; guard $rc
 cd $R
 DB=$(find gpurun_out/${TAG}_prof -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB gpurun_out/${TAG}_kernel_stats.csv 6 > gpurun_out/${TAG}_stats.txt
