@@ -396,7 +396,7 @@ def main():
                                  "note": "algorithmic bytes of the folded-projection form (12.6 MB/img forward, 33.5 MB/img backward at N=16384; the reference's "
                                          "materialised k|v form would move 75.5 MB/img forward); fwd / bwd = the chain on its own at the same shape, HIP events "
                                          "around its launches; pmc = matrix-pipe busy fraction / resident waves per SIMD / HBM bytes per launch from rocprofv3 counters"}
-    if world == 1 and args.workload == "slate" and not args.conv_x3 and not args.no_exploratory:
+    if world == 1 and not args.conv_x3 and not args.no_exploratory:
         # EXPLORATORY second pass, never `value`: the same step with the 5x5 / 64-channel convolutions (forward, backward-data, weight
         # gradient) on the bf16 matrix pipe, every fp32 operand split exactly into three bf16 numbers and six products accumulated in fp32
         # (csrc/conv_x3.hip).  The GPU parity suite passes unchanged with OCRL_CONV_X3=1 (profiles/r03_exploratory_conv_x3_gpu_suite.log).

@@ -302,8 +302,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
         const float* gx = p.X + (size_t)b * p.H * p.W * CIN;
 #pragma unroll
         for (int i = 0; i < NDY; ++i) {
+            // a wave covers 16 consecutive pixels x 4 channel quads, so that its transposed LDS stores hit 64 different banks
             const int idx = threadIdx.x + i * 256;
-            const int c4 = idx % FY, pp = idx / FY;
+            const int c4 = (idx >> 4) & 15, pp = ((idx >> 8) << 4) | (idx & 15);
             const int x = x0 + (pp % TW_), y = y0 + (pp / TW_);
             rdy[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (y < p.H && x < p.W) rdy[i] = *reinterpret_cast<const float4*>(gy + ((size_t)y * p.W + x) * COUT + c4 * 4);
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = threadIdx.x + i * 256;
-            const int c4 = idx % FX, hp = idx / FX;
+            const int c4 = (idx >> 4) & 15, hp = ((idx >> 8) << 4) | (idx & 15);
             const int x = x0 - P + (hp % HW_), y = y0 + ky - P + (hp / HW_);
             rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < XT && y >= 0 && y < p.H && x >= 0 && x < p.W) rx[i] = *reinterpret_cast<const float4*>(gx + ((size_t)y * p.W + x) * CIN + c4 * 4);
@@ -324,16 +325,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < NDY; ++i) {          // transposed stores: [channel][pixel]
-            const int idx = threadIdx.x + i * 256, c = (idx % FY) * 4, pp = idx / FY;
+            const int idx = threadIdx.x + i * 256, c = ((idx >> 4) & 15) * 4, pp = ((idx >> 8) << 4) | (idx & 15);
             dYt[(c + 0) * LDY + pp] = rdy[i].x; dYt[(c + 1) * LDY + pp] = rdy[i].y; dYt[(c + 2) * LDY + pp] = rdy[i].z; dYt[(c + 3) * LDY + pp] = rdy[i].w;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const int idx = threadIdx.x + i * 256, c = (idx % FX) * 4, hp = idx / FX;
+            const int idx = threadIdx.x + i * 256, c = ((idx >> 4) & 15) * 4, hp = ((idx >> 8) << 4) | (idx & 15);
             if (idx < XT) { Xt[(c + 0) * LDX + hp] = rx[i].x; Xt[(c + 1) * LDX + hp] = rx[i].y; Xt[(c + 2) * LDX + hp] = rx[i].z; Xt[(c + 3) * LDX + hp] = rx[i].w; }
         }
         __syncthreads();
-        if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);
         float4 na[2], nb[3];                  // raw values of the next (row, 16-pixel group)
         na[0] = *reinterpret_cast<const float4*>(arow); na[1] = *reinterpret_cast<const float4*>(arow + 4);
         nb[0] = *reinterpret_cast<const float4*>(brow); nb[1] = *reinterpret_cast<const float4*>(brow + 4); nb[2] = *reinterpret_cast<const float4*>(brow + 8);
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
             for (int i = 0; i < 6; ++i) { eh[i] = X3_PK(vh[2 * i + 1], vh[2 * i]); em[i] = X3_PK(vm[2 * i + 1], vm[2 * i]); el[i] = X3_PK(vl[2 * i + 1], vl[2 * i]); }
 #pragma unroll
             for (int i = 0; i < 5; ++i) { oh[i] = X3_PK(vh[2 * i + 2], vh[2 * i + 1]); om[i] = X3_PK(vm[2 * i + 2], vm[2 * i + 1]); ol[i] = X3_PK(vl[2 * i + 2], vl[2 * i + 1]); }
+            if (it == TH_ && t + (int)gridDim.x < ntiles) gload(t + gridDim.x);      // next tile: global -> registers, under the second half's MFMAs
             // ---- raw values of the next group
             if (it + 1 < TH_ * 2) {
                 const int rr = (it + 1) >> 1, g = (it + 1) & 1;

@@ -193,7 +193,14 @@ void SlateModel::layout_workspace(bool commit) {
         bc_c1_ = carve("bc_c1", BKN * 64); bc_c2_ = carve("bc_c2", BKN * 64); bc_c3_ = carve("bc_c3", BKN * 64);
         bc_out4_ = carve(nullptr, BKN * 4); bc_dout4_ = carve(nullptr, BKN * 4);
         bc_gA_ = carve(nullptr, BKN * 64); bc_gB_ = carve(nullptr, BKN * 64);
-        for (int i = 0; i < 2; ++i) { bc_pk_[i] = carve(nullptr, 25 * 64 * 64); bc_pkb_[i] = carve(nullptr, 25 * 64 * 64); }
+        for (int i = 0; i < 2; ++i) {
+            bc_pk_[i] = carve(nullptr, 25 * 64 * 64); bc_pkb_[i] = carve(nullptr, 25 * 64 * 64);
+            if (conv_x3_ > 0) {           // exploratory split-precision packs of the broadcast decoder's 5x5 / 64-channel layers
+                float* f3 = carve(nullptr, conv_x3_pack_floats());
+                float* b3 = carve(nullptr, conv_x3_pack_floats());
+                if (ws_commit_) { x3_of_[bc_pk_[i]] = f3; x3_of_[bc_pkb_[i]] = b3; }
+            }
+        }
         bc_Wk4_ = carve(nullptr, 9 * 64 * 4); bc_Wb4_ = carve(nullptr, 9 * 64 * 4);
         bc_dW1r_ = carve(nullptr, (size_t)25 * 64 * D); bc_dWc_ = carve(nullptr, 25 * 64 * 5 + 64);
         bc_dT_ = carve(nullptr, BK * 1600); bc_dM_ = carve(nullptr, BK * 1600); bc_G1_ = carve(nullptr, (size_t)N * 64);
@@ -1252,6 +1259,13 @@ int SlateModel::pack_bcdec(hipStream_t st) {
                          bc_W1r_, D, st));
     RC(conv_pack_launch(P("_dec._decoder.1.m.weight"), bc_pk_[0], bc_pkb_[0], 5, 64, 64, 64, st));
     RC(conv_pack_launch(P("_dec._decoder.2.m.weight"), bc_pk_[1], bc_pkb_[1], 5, 64, 64, 64, st));
+    if (conv_x3_ > 0) {
+        const char* names[2] = {"_dec._decoder.1.m.weight", "_dec._decoder.2.m.weight"};
+        for (int i = 0; i < 2; ++i) {
+            auto f = x3_of_.find(bc_pk_[i]), b = x3_of_.find(bc_pkb_[i]);
+            if (f != x3_of_.end()) RC(conv_pack_x3_launch(P(names[i]), const_cast<float*>(f->second), b != x3_of_.end() ? const_cast<float*>(b->second) : nullptr, st));
+        }
+    }
     RC(bc_c4_pack_launch(P("_dec._decoder.3.weight"), bc_Wk4_, bc_Wb4_, cfg.obs_channels + 1, st));
     return 0;
 }
