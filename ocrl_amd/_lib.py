@@ -69,9 +69,9 @@ def lib():
     L.ocrl_conv2d_fwd.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, p, p]
     L.ocrl_conv2d_fwd_lowlat.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, p, p]
     L.ocrl_conv2d_x3_ws_floats.restype = c_size_t
-    L.ocrl_conv2d_fwd_x3.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, p, p]
-    L.ocrl_conv2d_bwd_data_x3.argtypes = [p, p, p, p, c_int, c_int, c_int, p, p]
-    L.ocrl_conv2d_bwd_weight_x3.argtypes = [p, p, p, c_int, c_int, c_int, p, c_size_t, p]
+    L.ocrl_conv2d_fwd_x3.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, c_int, p, p]
+    L.ocrl_conv2d_bwd_data_x3.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, p, p]
+    L.ocrl_conv2d_bwd_weight_x3.argtypes = [p, p, p, c_int, c_int, c_int, c_int, p, c_size_t, p]
     L.ocrl_conv2d_bwd_data.argtypes = [p, p, p, p, c_int, c_int, c_int, c_int, p, p]
     L.ocrl_conv2d_wgrad_ws_floats.argtypes = [c_int, c_int, c_int, c_int, c_int]
     L.ocrl_conv2d_wgrad_ws_floats.restype = c_size_t

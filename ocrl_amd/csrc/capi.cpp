@@ -148,18 +148,20 @@ int ocrl_conv2d_fwd_lowlat(const float* x, const float* w, const float* bias, fl
     a.X = x; a.Wp = ws; a.Y = y; a.B = B; a.H = H; a.W = W; a.bias = bias; a.relu = relu;
     return conv_fwd_launch(a, ks, cin_pad, 64, ST(stream), 1);
 }
-size_t ocrl_conv2d_x3_ws_floats(void) { return 2 * conv_x3_pack_floats(); }
-int ocrl_conv2d_fwd_x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int relu, float* ws, void* stream) {
-    if (conv_pack_x3_launch(w, ws, nullptr, ST(stream))) return 1;
+size_t ocrl_conv2d_x3_ws_floats(void) { return 2 * conv_x3_pack_floats(5); }
+int ocrl_conv2d_fwd_x3(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int ks, int relu, float* ws, void* stream) {
+    if (ks != 3 && ks != 5) { ocrl_set_error("ocrl_conv2d_fwd_x3: ks must be 3 or 5"); return 1; }
+    if (conv_pack_x3_launch(w, ws, nullptr, ST(stream), ks)) return 1;
     ConvArgs a;
     a.X = x; a.Y = y; a.B = B; a.H = H; a.W = W; a.bias = bias; a.relu = relu;
-    return conv_x3_launch(a, ws, ST(stream));
+    return conv_x3_launch(a, ws, ST(stream), ks);
 }
-int ocrl_conv2d_bwd_data_x3(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, float* ws, void* stream) {
-    if (conv_pack_x3_launch(w, ws, ws + conv_x3_pack_floats(), ST(stream))) return 1;
+int ocrl_conv2d_bwd_data_x3(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream) {
+    if (ks != 3 && ks != 5) { ocrl_set_error("ocrl_conv2d_bwd_data_x3: ks must be 3 or 5"); return 1; }
+    if (conv_pack_x3_launch(w, ws, ws + conv_x3_pack_floats(5), ST(stream), ks)) return 1;
     ConvArgs a;
     a.X = dy; a.Y = dx; a.B = B; a.H = H; a.W = W; a.mask = mask;
-    return conv_x3_launch(a, ws + conv_x3_pack_floats(), ST(stream));
+    return conv_x3_launch(a, ws + conv_x3_pack_floats(5), ST(stream), ks);
 }
 int ocrl_conv2d_bwd_data(const float* dy, const float* w, const float* mask, float* dx, int B, int H, int W, int ks, float* ws, void* stream) {
     float* bw = ws + (size_t)ks * ks * 64 * 64;
@@ -178,11 +180,12 @@ int ocrl_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db
     if (db) return colsum_launch(dy, 64, db, (long long)B * H * W, 64, 0, 1.f, ws, ws_floats, ST(stream));
     return 0;
 }
-int ocrl_conv2d_bwd_weight_x3(const float* x, const float* dy, float* dw, int B, int H, int W, float* ws, size_t ws_floats, void* stream) {
-    if (ws_floats < ocrl_conv2d_wgrad_ws_floats(B, H, W, 5, 64)) { ocrl_set_error("ocrl_conv2d_bwd_weight_x3: workspace too small"); return 1; }
+int ocrl_conv2d_bwd_weight_x3(const float* x, const float* dy, float* dw, int B, int H, int W, int ks, float* ws, size_t ws_floats, void* stream) {
+    if (ks != 3 && ks != 5) { ocrl_set_error("ocrl_conv2d_bwd_weight_x3: ks must be 3 or 5"); return 1; }
+    if (ws_floats < ocrl_conv2d_wgrad_ws_floats(B, H, W, ks, 64)) { ocrl_set_error("ocrl_conv2d_bwd_weight_x3: workspace too small"); return 1; }
     WgradArgs a;
     a.X = x; a.dY = dy; a.part = ws; a.B = B; a.H = H; a.W = W;
-    return conv_wgrad_launch(a, 5, 64, 64, 64, dw, 0, ST(stream), 1);
+    return conv_wgrad_launch(a, ks, 64, 64, 64, dw, 0, ST(stream), 1);
 }
 int ocrl_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, long long R, int F, void* stream) {
     return layernorm_fwd_launch(x, g, b, y, mean, rstd, R, F, ST(stream));

@@ -519,7 +519,7 @@ int conv_wgrad_launch(const WgradArgs& a, int KS, int CIN, int COUT, int cin_rea
     if (x3_env < 0) { const char* e = getenv("OCRL_CONV_X3"); x3_env = e ? atoi(e) : 0; }
     if (x3 < 0) x3 = x3_env;
     int rc;
-    if (KS == 5 && CIN == 64 && x3 > 0) rc = conv_wgrad_x3_stage(a, nchunk, st);
+    if ((KS == 5 || KS == 3) && CIN == 64 && x3 > 0) rc = conv_wgrad_x3_stage(a, nchunk, st, KS);
     else if (KS == 5 && CIN == 64) rc = conv_wgrad_cfg<5, 64>(a, nchunk, st);
     else if (KS == 5 && CIN == 8) rc = conv_wgrad_cfg<5, 8>(a, nchunk, st);
     else if (KS == 3 && CIN == 64) rc = conv_wgrad_cfg<3, 64>(a, nchunk, st);

@@ -22,10 +22,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define X3_TH 8
 #define X3_TW 32
-#define X3_KS 5
-#define X3_HW (X3_TW + X3_KS - 1)
-#define X3_HH (X3_TH + X3_KS - 1)
-#define X3_LDH 68
 #define X3_NCH 4          // 16-channel chunks of the 64 input channels
 
 __device__ __forceinline__ uint32_t x3_hi(float x) { return __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u; }
@@ -52,8 +48,9 @@ __device__ __forceinline__ void x3_split(const float4& a, const float4& b, uint4
 // one workgroup's halo loads and epilogue run under the other's MFMAs and every SIMD holds two waves.
 #define X3_CP 32          // input channels per phase
 #define X3_LDP 36         // floats per halo pixel of a phase (32 + 4: conflict-free ds_read_b128 over 16 pixels)
+template <int KS>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs p, const uint4* __restrict__ Wp3) {
-    constexpr int KS = X3_KS, P = KS / 2, HW_ = X3_HW, HH_ = X3_HH, LDH = X3_LDP, NCL = X3_CP / 16, CIN = 64, COUT = 64;
+    constexpr int P = KS / 2, HW_ = X3_TW + KS - 1, HH_ = X3_TH + KS - 1, LDH = X3_LDP, NCL = X3_CP / 16, CIN = 64, COUT = 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tiles_x = (p.W + X3_TW - 1) / X3_TW, tiles_y = (p.H + X3_TH - 1) / X3_TH;
     int bid = blockIdx.x;
@@ -223,19 +220,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(ConvArgs p, const uint4
     }
 }
 
-// W [64][64][5][5] (reference layout) -> the split-precision packs: fwd[s][n][plane][lane] and, flipped / transposed for the
+// W [64][64][KS][KS] (reference layout) -> the split-precision packs: fwd[s][n][plane][lane] and, flipped / transposed for the
 // backward-data pass, bwd[..] (uint4 = eight bf16: k = 8*(lane>>5) + j of chunk c, column (lane & 31) of n-block n; s = tap*4 + c)
-__global__ void conv_pack_x3_kernel(const float* __restrict__ W, uint4* __restrict__ fwd, uint4* __restrict__ bwd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (s, n, lane)
-    if (i >= 25 * 4 * 2 * 64) return;
+__global__ void conv_pack_x3_kernel(const float* __restrict__ W, uint4* __restrict__ fwd, uint4* __restrict__ bwd, int KK) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (s, n, lane); KK = KS * KS taps
+    if (i >= KK * 4 * 2 * 64) return;
     const int lane = i & 63, n = (i >> 6) & 1, s = i >> 7, c = s & 3, tap = s >> 2;
     const int r = lane & 31, h = lane >> 5;
     float vf[8], vb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = c * 16 + 8 * h + j, col = n * 32 + r;
-        vf[j] = W[((size_t)col * 64 + k) * 25 + tap];                 // forward: B[k = ci][col = co]
-        vb[j] = W[((size_t)k * 64 + col) * 25 + (24 - tap)];          // backward data: B[k = co][col = ci] at the flipped tap
+        vf[j] = W[((size_t)col * 64 + k) * KK + tap];                 // forward: B[k = ci][col = co]
+        vb[j] = W[((size_t)k * 64 + col) * KK + (KK - 1 - tap)];      // backward data: B[k = co][col = ci] at the flipped tap
     }
     uint4 ph, pm, pl;
     x3_split(make_float4(vf[0], vf[1], vf[2], vf[3]), make_float4(vf[4], vf[5], vf[6], vf[7]), ph, pm, pl);
@@ -257,9 +254,10 @@ __global__ void conv_pack_x3_kernel(const float* __restrict__ W, uint4* __restri
 // registers, the X planes packed once for even and once for odd kx (the windows of neighbouring kx overlap by 7 pixels).
 #define WX_TH 4
 #define WX_TW 32
-#define WX_HW (WX_TW + X3_KS - 1)
 #define WX_LDY (WX_TH * WX_TW + 4)        // floats per co row of the transposed dY tile
-#define WX_LDX (WX_TH * WX_HW + 4)        // floats per ci row of the transposed X tile
+// transposed X tile: rows of HW = 32 + KS - 1 pixels stored at a stride of HWP (a multiple of 4, so every fragment read is 16-byte
+// aligned), LDX floats per ci row (+4: conflict-free reads)
+template <int KS> struct WxGeo { static constexpr int HW = WX_TW + KS - 1, HWP = (HW + 3) & ~3, NPX = WX_TH * HWP, LDX = NPX + 4, NV = KS + 7; };
 __device__ __forceinline__ void x3_planes(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
     h = x3_hi(v);
     const float r = v - __builtin_bit_cast(float, h);
@@ -268,8 +266,11 @@ __device__ __forceinline__ void x3_planes(float v, uint32_t& h, uint32_t& m, uin
 }
 #define X3_PK(hi_, lo_) __builtin_amdgcn_perm((hi_), (lo_), 0x07060302u)
 
+template <int KS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
-    constexpr int KS = X3_KS, P = KS / 2, HW_ = WX_HW, CIN = 64, COUT = 64, TH_ = WX_TH, TW_ = WX_TW, LDY = WX_LDY, LDX = WX_LDX;
+    constexpr int P = KS / 2, HW_ = WxGeo<KS>::HW, HWP = WxGeo<KS>::HWP, NPX = WxGeo<KS>::NPX, CIN = 64, COUT = 64, TH_ = WX_TH, TW_ = WX_TW,
+                  LDY = WX_LDY, LDX = WxGeo<KS>::LDX, NV = WxGeo<KS>::NV, NE = NV / 2, NO = NV / 2 - 1;
+    static_assert(KS == 3 || KS == 5, "window of 8 + KS - 1 pixels inside three float4");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dYt = smem;                    // [COUT][LDY]: dY tile, pixel index = row * 32 + x
     float* Xt = smem + COUT * LDY;        // [CIN][LDX]: X tile rows shifted by ky, pixel index = row * 36 + hx
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
     constexpr int FY = COUT / 4, FX = CIN / 4;
-    constexpr int NDY = (TH_ * TW_ * FY + 255) / 256, XT = TH_ * HW_ * FX, NX = (XT + 255) / 256;
+    constexpr int NDY = (TH_ * TW_ * FY + 255) / 256, NX = (NPX + 15) / 16;      // one float4 per (pixel, channel quad): 256 per 16 pixels
     float4 rdy[NDY], rx[NX];
     auto gload = [&](int t) {
         int q = t;
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
         for (int i = 0; i < NX; ++i) {
             const int idx = threadIdx.x + i * 256;
             const int c4 = (idx >> 4) & 15, hp = ((idx >> 8) << 4) | (idx & 15);
-            const int x = x0 - P + (hp % HW_), y = y0 + ky - P + (hp / HW_);
+            const int hx = hp % HWP, x = x0 - P + hx, y = y0 + ky - P + (hp / HWP);
             rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < XT && y >= 0 && y < p.H && x >= 0 && x < p.W) rx[i] = *reinterpret_cast<const float4*>(gx + ((size_t)y * p.W + x) * CIN + c4 * 4);
+            if (hp < NPX && hx < HW_ && y >= 0 && y < p.H && x >= 0 && x < p.W) rx[i] = *reinterpret_cast<const float4*>(gx + ((size_t)y * p.W + x) * CIN + c4 * 4);
         }
     };
     const float* arow = dYt + (coh * 32 + li) * LDY + 8 * lh;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int idx = threadIdx.x + i * 256, c = ((idx >> 4) & 15) * 4, hp = ((idx >> 8) << 4) | (idx & 15);
-            if (idx < XT) { Xt[(c + 0) * LDX + hp] = rx[i].x; Xt[(c + 1) * LDX + hp] = rx[i].y; Xt[(c + 2) * LDX + hp] = rx[i].z; Xt[(c + 3) * LDX + hp] = rx[i].w; }
+            if (hp < NPX) { Xt[(c + 0) * LDX + hp] = rx[i].x; Xt[(c + 1) * LDX + hp] = rx[i].y; Xt[(c + 2) * LDX + hp] = rx[i].z; Xt[(c + 3) * LDX + hp] = rx[i].w; }
         }
         __syncthreads();
         float4 na[2], nb[3];                  // raw values of the next (row, 16-pixel group)
@@ -343,20 +344,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
             uint4 ah, am, al;
             x3_split(na[0], na[1], ah, am, al);
             const float v[12] = {nb[0].x, nb[0].y, nb[0].z, nb[0].w, nb[1].x, nb[1].y, nb[1].z, nb[1].w, nb[2].x, nb[2].y, nb[2].z, nb[2].w};
-            uint32_t vh[12], vm[12], vl[12];
+            uint32_t vh[NV], vm[NV], vl[NV];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) x3_planes(v[k], vh[k], vm[k], vl[k]);
-            uint32_t eh[6], em[6], el[6], oh[5], om[5], ol[5];       // pairs (2i, 2i+1) and (2i+1, 2i+2)
+            for (int k = 0; k < NV; ++k) x3_planes(v[k], vh[k], vm[k], vl[k]);
+            uint32_t eh[NE], em[NE], el[NE], oh[NO], om[NO], ol[NO];       // pairs (2i, 2i+1) and (2i+1, 2i+2)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { eh[i] = X3_PK(vh[2 * i + 1], vh[2 * i]); em[i] = X3_PK(vm[2 * i + 1], vm[2 * i]); el[i] = X3_PK(vl[2 * i + 1], vl[2 * i]); }
+            for (int i = 0; i < NE; ++i) { eh[i] = X3_PK(vh[2 * i + 1], vh[2 * i]); em[i] = X3_PK(vm[2 * i + 1], vm[2 * i]); el[i] = X3_PK(vl[2 * i + 1], vl[2 * i]); }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { oh[i] = X3_PK(vh[2 * i + 2], vh[2 * i + 1]); om[i] = X3_PK(vm[2 * i + 2], vm[2 * i + 1]); ol[i] = X3_PK(vl[2 * i + 2], vl[2 * i + 1]); }
+            for (int i = 0; i < NO; ++i) { oh[i] = X3_PK(vh[2 * i + 2], vh[2 * i + 1]); om[i] = X3_PK(vm[2 * i + 2], vm[2 * i + 1]); ol[i] = X3_PK(vl[2 * i + 2], vl[2 * i + 1]); }
             if (it == TH_ && t + (int)gridDim.x < ntiles) gload(t + gridDim.x);      // next tile: global -> registers, under the second half's MFMAs
             // ---- raw values of the next group
             if (it + 1 < TH_ * 2) {
                 const int rr = (it + 1) >> 1, g = (it + 1) & 1;
                 const float* an = arow + rr * TW_ + g * 16;
-                const float* bn = brow + rr * HW_ + g * 16;
+                const float* bn = brow + rr * HWP + g * 16;
                 na[0] = *reinterpret_cast<const float4*>(an); na[1] = *reinterpret_cast<const float4*>(an + 4);
                 nb[0] = *reinterpret_cast<const float4*>(bn); nb[1] = *reinterpret_cast<const float4*>(bn + 4); nb[2] = *reinterpret_cast<const float4*>(bn + 8);
             }
@@ -387,40 +388,55 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradArgs p) {
             out[((size_t)kx * COUT + co) * CIN + cih * 32 + li] = acc[kx][r];
         }
 }
-int conv_wgrad_x3_stage(const WgradArgs& a, int nchunk, hipStream_t st) {
-    constexpr int smem = (64 * WX_LDY + 64 * WX_LDX) * 4;
+template <int KS>
+static int conv_wgrad_x3_cfg(const WgradArgs& a, int nchunk, hipStream_t st) {
+    constexpr int smem = (64 * WX_LDY + 64 * WxGeo<KS>::LDX) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        OCRL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_x3_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int pi = prof_begin(PROF_WGRAD, st);
-    hipLaunchKernelGGL(conv_wgrad_x3_kernel, dim3(nchunk, X3_KS), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(conv_wgrad_x3_kernel<KS>, dim3(nchunk, KS), dim3(256), smem, st, a);
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("conv_wgrad_x3_kernel");
     return 0;
 }
+int conv_wgrad_x3_stage(const WgradArgs& a, int nchunk, hipStream_t st, int KS) {
+    if (KS == 5) return conv_wgrad_x3_cfg<5>(a, nchunk, st);
+    if (KS == 3) return conv_wgrad_x3_cfg<3>(a, nchunk, st);
+    ocrl_set_error("conv wgrad x3: unsupported KS=%d", KS);
+    return 1;
+}
 
-size_t conv_x3_pack_floats() { return (size_t)25 * 4 * 2 * 3 * 64 * 4; }      // floats per pack (614 KB)
-int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st) {
-    hipLaunchKernelGGL(conv_pack_x3_kernel, dim3(cdiv(25 * 4 * 2 * 64, 256)), dim3(256), 0, st, W, reinterpret_cast<uint4*>(fwd3), reinterpret_cast<uint4*>(bwd3));
+size_t conv_x3_pack_floats(int KS) { return (size_t)KS * KS * 4 * 2 * 3 * 64 * 4; }      // floats per pack (614 KB at 5x5)
+int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st, int KS) {
+    hipLaunchKernelGGL(conv_pack_x3_kernel, dim3(cdiv(KS * KS * 4 * 2 * 64, 256)), dim3(256), 0, st, W, reinterpret_cast<uint4*>(fwd3), reinterpret_cast<uint4*>(bwd3),
+                       KS * KS);
     OCRL_CHECK_LAUNCH("conv_pack_x3");
     return 0;
 }
-int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st) {
-    OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && pack3, "conv x3: empty input / missing pack");
-    OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)pack3 & 15) == 0, "conv x3: X / pack must be 16-byte aligned");
-    constexpr int smem = X3_HH * X3_HW * X3_LDP * 4;
-    static_assert(X3_HH * X3_HW * X3_LDP >= 4 * 32 * 68, "the halo region must hold the four epilogue patches");
+template <int KS>
+static int conv_x3_cfg(const ConvArgs& a, const float* pack3, hipStream_t st) {
+    constexpr int smem = (X3_TH + KS - 1) * (X3_TW + KS - 1) * X3_LDP * 4;
+    static_assert((X3_TH + KS - 1) * (X3_TW + KS - 1) * X3_LDP >= 4 * 32 * 68, "the halo region must hold the four epilogue patches");
     static bool attr_set = false;
     if (!attr_set) {
-        OCRL_HIP(hipFuncSetAttribute((const void*)conv_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        OCRL_HIP(hipFuncSetAttribute((const void*)conv_x3_kernel<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int grid = cdiv(a.W, X3_TW) * cdiv(a.H, X3_TH) * a.B;
-    const int pi = prof_begin(PROF_CONV5, st);
-    hipLaunchKernelGGL(conv_x3_kernel, dim3(grid), dim3(256), smem, st, a, reinterpret_cast<const uint4*>(pack3));
+    const int pi = prof_begin(KS == 5 ? PROF_CONV5 : PROF_CONV_OTHER, st);
+    hipLaunchKernelGGL(conv_x3_kernel<KS>, dim3(grid), dim3(256), smem, st, a, reinterpret_cast<const uint4*>(pack3));
     prof_end(pi, st);
     OCRL_CHECK_LAUNCH("conv_x3_kernel");
     return 0;
+}
+int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st, int KS) {
+    OCRL_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && pack3, "conv x3: empty input / missing pack");
+    OCRL_REQUIRE(((uintptr_t)a.X & 15) == 0 && ((uintptr_t)pack3 & 15) == 0, "conv x3: X / pack must be 16-byte aligned");
+    if (KS == 5) return conv_x3_cfg<5>(a, pack3, st);
+    if (KS == 3) return conv_x3_cfg<3>(a, pack3, st);
+    ocrl_set_error("conv x3: unsupported KS=%d", KS);
+    return 1;
 }

@@ -7,6 +7,7 @@
 #include "iodine_model.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 #define RC(x)                 \
     do {                      \
@@ -105,6 +106,9 @@ void IodineModel::layout_workspace(bool commit) {
     M_ = carve(nullptr, BK * 576); T_ = carve(nullptr, BK * 576);
     P1_ = carve(nullptr, (size_t)N * 64); W1r_ = carve(nullptr, (size_t)576 * L); Wxy_ = carve(nullptr, 576 * 2);
     for (int l = 0; l < 3; ++l) { pk_[l] = carve(nullptr, 9 * 64 * 64); pkb_[l] = carve(nullptr, 9 * 64 * 64); }
+    if (conv_x3_ < 0) { const char* e = getenv("OCRL_CONV_X3"); conv_x3_ = e ? atoi(e) : 0; }
+    if (conv_x3_ > 0)
+        for (int l = 0; l < 3; ++l) { pk3_[l] = carve(nullptr, conv_x3_pack_floats(3)); pkb3_[l] = carve(nullptr, conv_x3_pack_floats(3)); }
     Wk4_ = carve(nullptr, 9 * 64 * 4); Wb4_ = carve(nullptr, 9 * 4 * 64);
     size_t colmax = 0;
     for (int l = 0; l < 4; ++l) {
@@ -197,6 +201,8 @@ int IodineModel::pack_weights(hipStream_t st) {
     RC(io_w1_pack_launch(P("decoder.mlc.layers.0.weight"), W1r_, Wxy_, L, st));
     RC(io_p1_launch(Wxy_, P("decoder.mlc.layers.0.bias"), P1_, S, st));
     for (int l = 0; l < 3; ++l) RC(conv_pack_launch(P(ifmt("decoder.mlc.layers.%d.weight", l + 1)), pk_[l], pkb_[l], 3, 64, 64, 64, st));
+    if (conv_x3_ > 0)
+        for (int l = 0; l < 3; ++l) RC(conv_pack_x3_launch(P(ifmt("decoder.mlc.layers.%d.weight", l + 1)), pk3_[l], pkb3_[l], st, 3));
     RC(bc_c4_pack_launch(P("decoder.conv.weight"), Wk4_, Wb4_, 4, st));
     for (int l = 0; l < 4; ++l) RC(io_refw_pack_launch(P(ifmt("refine.mlc.layers.%d.weight", l)), Wp_[l], l ? 64 : 17, ldc_[l], st));
     return 0;
@@ -211,6 +217,7 @@ int IodineModel::decoder_fwd(int i, hipStream_t st) {
         ConvArgs a;
         a.X = c_[l][i]; a.Wp = pk_[l]; a.Y = c_[l + 1][i]; a.B = (int)BK; a.H = S; a.W = S; a.relu = 2;
         a.bias = P(ifmt("decoder.mlc.layers.%d.bias", l + 1));
+        if (conv_x3_ > 0) RC(conv_x3_launch(a, pk3_[l], st, 3)); else
         RC(conv_fwd_launch(a, 3, 64, 64, st));
     }
     RC(bc_c4_fwd_launch(c_[3][i], Wk4_, P("decoder.conv.bias"), out4_[i], (int)BK, S, st));
@@ -234,11 +241,12 @@ int IodineModel::decoder_bwd(int i, const float* dout4, bool weights, hipStream_
             WgradArgs w;
             w.X = c_[l][i]; w.dY = cur; w.part = scratch_; w.B = (int)BK; w.H = S; w.W = S;
             OCRL_REQUIRE(conv_wgrad_ws_floats((int)BK, S, S, 3, 64) <= scratch_floats_, "conv wgrad: scratch too small");
-            RC(conv_wgrad_launch(w, 3, 64, 64, 64, G(ifmt("decoder.mlc.layers.%d.weight", l + 1)), 1, st));
+            RC(conv_wgrad_launch(w, 3, 64, 64, 64, G(ifmt("decoder.mlc.layers.%d.weight", l + 1)), 1, st, conv_x3_ > 0 ? 1 : 0));
             RC(colsum_launch(cur, 64, G(ifmt("decoder.mlc.layers.%d.bias", l + 1)), BKN, 64, 1, 1.f, scratch_, scratch_floats_, st));
         }
         ConvArgs a;
         a.X = cur; a.Wp = pkb_[l]; a.Y = nxt; a.B = (int)BK; a.H = S; a.W = S; a.mask = c_[l][i]; a.mask_elu = 1;
+        if (conv_x3_ > 0) RC(conv_x3_launch(a, pkb3_[l], st, 3)); else
         RC(conv_fwd_launch(a, 3, 64, 64, st));                                                        // d pre-activation of layer l
         float* t = cur; cur = nxt; nxt = t;
     }

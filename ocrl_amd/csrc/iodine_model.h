@@ -66,6 +66,8 @@ private:
     bool have_fwd_ = false;
 
     float *scratch_ = nullptr; size_t scratch_floats_ = 0;
+    int conv_x3_ = -1;                    // OCRL_CONV_X3=1 (exploratory): the decoder's 3x3 / 64-channel layers on the split-precision bf16 kernels
+    float *pk3_[3] = {nullptr, nullptr, nullptr}, *pkb3_[3] = {nullptr, nullptr, nullptr};
     float* parts_ = nullptr;                  // [I][4]: ll, mse, kl sums
     float *st1_, *st2_;
     std::vector<float*> mu_, ls_, eps_, slots_, c_[4], out4_;

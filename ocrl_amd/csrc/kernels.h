@@ -79,11 +79,11 @@ struct ConvArgs {
     int mask_elu = 0;               // mask holds ELU outputs: v *= (m > 0 ? 1 : m + 1)
 };
 // conv_x3.hip (exploratory): the 5x5 / 64-channel layer on the bf16 matrix pipe with every fp32 operand split exactly into three bf16
-size_t conv_x3_pack_floats();
-int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st);          // W [64][64][5][5]; bwd3 may be null
-int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st);
+size_t conv_x3_pack_floats(int KS = 5);
+int conv_pack_x3_launch(const float* W, float* fwd3, float* bwd3, hipStream_t st, int KS = 5);          // W [64][64][KS][KS]; bwd3 may be null
+int conv_x3_launch(const ConvArgs& a, const float* pack3, hipStream_t st, int KS = 5);                   // KS = 5 or 3
 struct WgradArgs;
-int conv_wgrad_x3_stage(const WgradArgs& a, int nchunk, hipStream_t st);       // first stage of conv_wgrad_launch (same partial slabs)
+int conv_wgrad_x3_stage(const WgradArgs& a, int nchunk, hipStream_t st, int KS = 5);       // first stage of conv_wgrad_launch (same partial slabs)
 struct WgradArgs {
     const float* X = nullptr;       // [B,H,W,CIN]
     const float* dY = nullptr;      // [B,H,W,COUT]

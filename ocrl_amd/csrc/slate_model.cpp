@@ -225,7 +225,14 @@ void SlateModel::layout_workspace(bool commit) {
     dd6_ = carve("dvae_dec6", BT * 256); dd7_ = carve("dvae_dec7", BT * 256); dd8_ = carve("dvae_dec8", BT * 256);
     dd9_ = carve("dvae_dec9", BT * 1024); ps2_ = carve(nullptr, BN * 64);
     recon_ = carve("recon", BN * 4); drecon_ = carve(nullptr, BN * 4);
-    for (int i = 0; i < 2; ++i) { dw_fwd_[i] = carve(nullptr, 9 * 64 * 64); dw_bwd_[i] = carve(nullptr, 9 * 64 * 64); }
+    for (int i = 0; i < 2; ++i) {
+        dw_fwd_[i] = carve(nullptr, 9 * 64 * 64); dw_bwd_[i] = carve(nullptr, 9 * 64 * 64);
+        if (conv_x3_ > 0) {           // exploratory split-precision packs of the dVAE decoder's 3x3 / 64-channel layers
+            float* f3 = carve(nullptr, conv_x3_pack_floats(3));
+            float* b3 = carve(nullptr, conv_x3_pack_floats(3));
+            if (ws_commit_) { x3_of_[dw_fwd_[i]] = f3; x3_of_[dw_bwd_[i]] = b3; }
+        }
+    }
     w11p_ = carve(nullptr, 4 * 64);
     mem_ = carve("mem", BK * d); emb_ = carve("emb", BT * d);
     for (int b = 0; b < NB; ++b) {
@@ -432,9 +439,9 @@ int SlateModel::conv_layer_fwd(const float* x, const float* pack, const float* b
                                int relu, const float* posmap, const float* mask, hipStream_t st) {
     ConvArgs a;
     a.X = x; a.Wp = pack; a.Y = y; a.B = Bn; a.H = Hh; a.W = Ww; a.bias = bias; a.relu = relu; a.posmap = posmap; a.mask = mask;
-    if (conv_x3_ > 0 && KS == 5 && CIN == 64 && !conv_lowlat_) {
+    if (conv_x3_ > 0 && (KS == 5 || KS == 3) && CIN == 64 && !conv_lowlat_) {
         auto it = x3_of_.find(pack);
-        if (it != x3_of_.end()) return conv_x3_launch(a, it->second, st);
+        if (it != x3_of_.end()) return conv_x3_launch(a, it->second, st, KS);
     }
     return conv_fwd_launch(a, KS, CIN, 64, st, conv_lowlat_);
 }
@@ -463,6 +470,13 @@ int SlateModel::pack_weights(hipStream_t st, bool encoder_only) {
     if (!cfg.use_bcdec && !encoder_only) {
         RC(conv_pack_launch(P("_dvae._decoder.1.m.weight"), dw_fwd_[0], dw_bwd_[0], 3, 64, 64, 64, st));
         RC(conv_pack_launch(P("_dvae._decoder.6.m.weight"), dw_fwd_[1], dw_bwd_[1], 3, 64, 64, 64, st));
+        if (conv_x3_ > 0) {
+            const char* names[2] = {"_dvae._decoder.1.m.weight", "_dvae._decoder.6.m.weight"};
+            for (int i = 0; i < 2; ++i) {
+                auto f = x3_of_.find(dw_fwd_[i]), b = x3_of_.find(dw_bwd_[i]);
+                if (f != x3_of_.end()) RC(conv_pack_x3_launch(P(names[i]), const_cast<float*>(f->second), b != x3_of_.end() ? const_cast<float*>(b->second) : nullptr, st, 3));
+            }
+        }
         RC(copy_launch(P("_dvae._decoder.11.weight"), w11p_, cfg.obs_channels * 64, st));    // [3,64] -> [4,64], row 3 zero
         RC(fill_launch(w11p_ + cfg.obs_channels * 64, (4 - cfg.obs_channels) * 64, 0.f, st));
     }

@@ -132,47 +132,47 @@ def test_conv_fwd_low_latency_variant(L, B, H, W, relu):
     assert torch.isfinite(y).all() and e < TOL and e0 < TOL
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 16, 16), (1, 64, 64), (3, 21, 44), (2, 128, 128)])
-def test_conv_split_precision_exploratory(L, B, H, W):
-    """csrc/conv_x3.hip (exploratory, not on a default path): the 5x5 / 64-channel layer on the bf16 matrix pipe with every fp32 operand
+@pytest.mark.parametrize("B,H,W,ks", [(2, 16, 16, 5), (1, 64, 64, 5), (3, 21, 44, 5), (2, 128, 128, 5), (2, 16, 16, 3), (3, 21, 44, 3), (2, 64, 64, 3)])
+def test_conv_split_precision_exploratory(L, B, H, W, ks):
+    """csrc/conv_x3.hip (exploratory, not on a default path): the 5x5 (3x3) / 64-channel layer on the bf16 matrix pipe with every fp32 operand
     split exactly into three bf16 numbers, six products accumulated in fp32 -- forward (bias + ReLU) and backward-data (ReLU mask) must
     hold the fp32 kernels' tolerance against fp64, i.e. it is fp32-equivalent arithmetic, not bf16 arithmetic"""
     g = torch.Generator().manual_seed(B * H + W)
     x = torch.randn(B, 64, H, W, generator=g) * torch.exp(2.0 * torch.randn(B, 64, H, W, generator=g))     # magnitudes over several binades
-    w = torch.randn(64, 64, 5, 5, generator=g) / 40.0
+    w = torch.randn(64, 64, ks, ks, generator=g) / (8.0 * ks)
     b = torch.randn(64, generator=g)
-    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=2))
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=ks // 2))
     xd, wd, bd = dev(nhwc(x)), dev(w), dev(b)
     y, y0 = torch.full((B, H, W, 64), float("nan"), device="cuda"), torch.empty(B, H, W, 64, device="cuda")
     ws = torch.empty(L.lib().ocrl_conv2d_x3_ws_floats(), device="cuda")
     ws0 = torch.empty(2 * 25 * 64 * 64, device="cuda")
-    L.check(L.lib().ocrl_conv2d_fwd_x3(P(xd), P(wd), P(bd), P(y), B, H, W, 1, P(ws), None))
-    L.check(L.lib().ocrl_conv2d_fwd(P(xd), P(wd), P(bd), P(y0), B, H, W, 64, 64, 5, 1, P(ws0), None))
+    L.check(L.lib().ocrl_conv2d_fwd_x3(P(xd), P(wd), P(bd), P(y), B, H, W, ks, 1, P(ws), None))
+    L.check(L.lib().ocrl_conv2d_fwd(P(xd), P(wd), P(bd), P(y0), B, H, W, 64, 64, ks, 1, P(ws0), None))
     torch.cuda.synchronize()
     e, e0 = relerr(y.cpu().permute(0, 3, 1, 2), ref), relerr(y0.cpu().permute(0, 3, 1, 2), ref)
     # backward data with a ReLU mask
     dy = torch.randn(B, 64, H, W, generator=g)
     act = torch.randn(B, 64, H, W, generator=g)
     xg = torch.zeros(B, 64, H, W, dtype=torch.double, requires_grad=True)
-    F.conv2d(xg, w.double(), None, padding=2).backward(dy.double())
+    F.conv2d(xg, w.double(), None, padding=ks // 2).backward(dy.double())
     refb = xg.grad * (act > 0)
     dyd, actd = dev(nhwc(dy)), dev(nhwc(act))
     dx, dx0 = torch.full((B, H, W, 64), float("nan"), device="cuda"), torch.empty(B, H, W, 64, device="cuda")
-    L.check(L.lib().ocrl_conv2d_bwd_data_x3(P(dyd), P(wd), P(actd), P(dx), B, H, W, P(ws), None))
-    L.check(L.lib().ocrl_conv2d_bwd_data(P(dyd), P(wd), P(actd), P(dx0), B, H, W, 5, P(ws0), None))
+    L.check(L.lib().ocrl_conv2d_bwd_data_x3(P(dyd), P(wd), P(actd), P(dx), B, H, W, ks, P(ws), None))
+    L.check(L.lib().ocrl_conv2d_bwd_data(P(dyd), P(wd), P(actd), P(dx0), B, H, W, ks, P(ws0), None))
     torch.cuda.synchronize()
     eb, eb0 = relerr(dx.cpu().permute(0, 3, 1, 2), refb), relerr(dx0.cpu().permute(0, 3, 1, 2), refb)
     # weight gradient
-    wg = torch.zeros(64, 64, 5, 5, dtype=torch.double, requires_grad=True)
-    F.conv2d(x.double(), wg, None, padding=2).backward(dy.double())
-    n = L.lib().ocrl_conv2d_wgrad_ws_floats(B, H, W, 5, 64)
+    wg = torch.zeros(64, 64, ks, ks, dtype=torch.double, requires_grad=True)
+    F.conv2d(x.double(), wg, None, padding=ks // 2).backward(dy.double())
+    n = L.lib().ocrl_conv2d_wgrad_ws_floats(B, H, W, ks, 64)
     wsw = torch.empty(n, device="cuda")
-    dw, dw0 = torch.full((64, 64, 5, 5), float("nan"), device="cuda"), torch.empty(64, 64, 5, 5, device="cuda")
-    L.check(L.lib().ocrl_conv2d_bwd_weight_x3(P(xd), P(dyd), P(dw), B, H, W, P(wsw), n, None))
-    L.check(L.lib().ocrl_conv2d_bwd_weight(P(xd), P(dyd), P(dw0), None, B, H, W, 64, 64, 5, P(wsw), n, None))
+    dw, dw0 = torch.full((64, 64, ks, ks), float("nan"), device="cuda"), torch.empty(64, 64, ks, ks, device="cuda")
+    L.check(L.lib().ocrl_conv2d_bwd_weight_x3(P(xd), P(dyd), P(dw), B, H, W, ks, P(wsw), n, None))
+    L.check(L.lib().ocrl_conv2d_bwd_weight(P(xd), P(dyd), P(dw0), None, B, H, W, 64, 64, ks, P(wsw), n, None))
     torch.cuda.synchronize()
     ew, ew0 = relerr(dw.cpu(), wg.grad), relerr(dw0.cpu(), wg.grad)
-    log(f"conv 5x5 split-precision (3 x bf16, 6 products) B{B} {H}x{W}: forward {e:.2e} (fp32 MFMA kernel {e0:.2e}), backward-data {eb:.2e} ({eb0:.2e}), "
+    log(f"conv {ks}x{ks} split-precision (3 x bf16, 6 products) B{B} {H}x{W}: forward {e:.2e} (fp32 MFMA kernel {e0:.2e}), backward-data {eb:.2e} ({eb0:.2e}), "
         f"weight gradient {ew:.2e} ({ew0:.2e}) vs fp64")
     assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(dw).all()
     assert e < TOL and eb < TOL and ew < TOL
