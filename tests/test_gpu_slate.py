@@ -443,6 +443,43 @@ def test_side_stream_overlap_matches_single_stream(monkeypatch):
         assert torch.equal(outs[0][1], o[1])          # the stream a kernel runs on does not change its arithmetic
 
 
+def test_execution_switches_agree(monkeypatch):
+    """The other per-engine execution switches against the default build on one training-mode step (device dropout, injected noise):
+    OCRL_DW_SIDE=0 / 1 (weight-gradient products on the main stream / the dVAE side stream instead of their own) must not change a bit;
+    OCRL_XATTN=0 (unfused cross-attention kernels instead of the folded form) and OCRL_CONV_X3=1 (exploratory split-precision
+    convolutions) are other summation orders of the same arithmetic: losses to 1e-6, every gradient to 2e-5 of the largest."""
+    cfg = O.default_cfg(**MID)
+    B = 3
+    P = O.formula_params(cfg)
+    obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(3)).cuda()
+    noise = dev_noise(cfg, O.make_noise(cfg, B, 9))
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = make_engine(cfg, B)
+        load_params(eng, P)
+        for _ in range(2):
+            eng.forward(obs, 0.9, train=True, seed=5, noise=noise)
+            eng.backward()
+        torch.cuda.synchronize()
+        for k in env:
+            monkeypatch.delenv(k)
+        return eng.metrics.cpu().clone(), eng.flat_g.cpu().clone()
+
+    m0, g0 = run({})
+    gmax = g0.abs().max()
+    for env, exact in (({"OCRL_DW_SIDE": "0"}, True), ({"OCRL_DW_SIDE": "1"}, True), ({"OCRL_XATTN": "0"}, False), ({"OCRL_CONV_X3": "1"}, False)):
+        m, g = run(env)
+        d = float((g - g0).abs().max() / gmax)
+        log(f"[switch {env}] loss {float(m[2]):.6f} vs {float(m0[2]):.6f}; gradient difference {d:.2e} of the largest gradient")
+        assert torch.allclose(m[:3], m0[:3], rtol=1e-6)
+        if exact:
+            assert torch.equal(g, g0), env
+        else:
+            assert 0.0 < d < 2e-5, (env, d)          # a different kernel really ran, and agrees
+
+
 def test_full_size_batch_additivity():
     """BASELINE config A shapes (128x128, 6 slots, 3 iterations, vocab 4096, 4 decoder blocks) are beyond the CPU oracle's reach in
     a test; the domain's size-independent property is additivity over images: every loss is sum/B and no operator mixes images, so
