@@ -1,5 +1,5 @@
-// EXPLORATORY (OCRL_CONV_X3=1, never the default, never the headline bench line): the 5x5 / 64-channel convolution on the bf16 matrix
-// pipe with fp32-equivalent split precision.  gfx950 has no xf32 / tf32 MFMA and the fp32 MFMA runs at 1/16 of the bf16 rate, so the
+// EXPLORATORY (OCRL_CONV_X3=1, never the default, never the headline bench line): the 5x5 and 3x3 / 64-channel convolutions (forward,
+// backward data, weight gradient) on the bf16 matrix pipe with fp32-equivalent split precision.  gfx950 has no xf32 / tf32 MFMA and the fp32 MFMA runs at 1/16 of the bf16 rate, so the
 // fp32 convolutions (0.87 of that peak) cannot get faster on it.  Here every fp32 operand is written as the EXACT sum of three bf16
 // numbers, x = h + m + l (h = the top 8 significant bits by truncation, m the next 8, l the last 8: both subtractions are exact in
 // fp32), and x*w is accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 products

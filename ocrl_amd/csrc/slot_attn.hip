@@ -1453,10 +1453,9 @@ __global__ void pack_kernel(const PackEntry* __restrict__ ent, float* __restrict
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (e.transpose >= 2) {     // tiled for the slot-side matrix products (MvJob): Wn[col][k] -> [col / 16][k / 16][16 * ((k % 16) / 4) + col % 16][k % 4]
             // mode 2: Wn = src ([rows = columns of the product][cols = k]);  mode 3: Wn = src^T
-            const int NCt = e.transpose == 2 ? e.rows : e.cols, Et = e.transpose == 2 ? e.cols : e.rows, nks = Et >> 4;
+            const int Et = e.transpose == 2 ? e.cols : e.rows, nks = Et >> 4;
             const int j = i & 3, lane = (i >> 2) & 63, rest = i >> 8, s = rest % nks, tile = rest / nks;
             const int col = tile * 16 + (lane & 15), k = s * 16 + (lane >> 4) * 4 + j;
-            (void)NCt;
             dst[e.dst_off + i] = e.transpose == 2 ? e.src[col * Et + k] : e.src[k * e.cols + col];
         } else if (e.transpose) {      // dst[c][r] = src[r][c], i enumerates dst
             const int c = i / e.rows, r = i - c * e.rows;
