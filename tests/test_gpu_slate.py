@@ -344,7 +344,8 @@ BC32 = dict(obs_size=32, vocab_size=256, num_slots=4, num_iterations=2, num_dec_
 BC12 = dict(obs_size=16, vocab_size=256, num_slots=12, num_iterations=2, num_dec_blocks=1, use_bcdec=True)      # more than 8 slots
 
 
-@pytest.mark.parametrize("tag,over,B", [("bcdec16", BC, 2), ("bcdec32", BC32, 3), ("bcdec_k12", BC12, 2)])
+@pytest.mark.parametrize("tag,over,B", [("bcdec16", BC, 2), ("bcdec32", BC32, 3), ("bcdec_k12", BC12, 2),
+                                         ("bcdec_heads2", dict(BC, num_slot_heads=2), 2), ("bcdec32_heads4", dict(BC32, num_slot_heads=4), 2)])
 def test_broadcast_decoder_config_matches_oracle(tag, over, B):
     """Slot-Attention configuration (use_bcdec): loss, reconstruction, every gradient, then two update() steps"""
     cfg = O.default_cfg(**over)
