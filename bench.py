@@ -273,6 +273,8 @@ def bench_iodine(args, dev, dist, rank, world):
                                   "fp32 accumulate; everything else as the headline (fp32 MFMA)",
                     "final_loss": round(float(lx.item()), 4),
                     "note": "not the graded number: opt-in (OCRL_CONV_X3=1 / --conv-x3); parity suite green with it enabled"}
+            except Exception as e:          # the exploratory pass must never cost the headline line
+                out["exploratory_conv_x3"] = {"error": repr(e)}
             finally:
                 os.environ.pop("OCRL_CONV_X3", None)
         if world == 1 and not args.no_cpu_baseline:
@@ -441,6 +443,8 @@ def main():
                               "fp32 accumulate; everything else as the headline (fp32 MFMA)",
                 "final_loss": float(mx["loss"].item()),
                 "note": "not the graded number: opt-in (OCRL_CONV_X3=1 / --conv-x3); parity suite green with it enabled"}
+        except Exception as e:          # the exploratory pass must never cost the headline line
+            out["exploratory_conv_x3"] = {"error": repr(e)}
         finally:
             os.environ.pop("OCRL_CONV_X3", None)
     if world == 1 and not args.no_cpu_baseline:
