@@ -10,6 +10,7 @@
 // Layers 2-3 reuse conv.hip; the 64->4 output convolution and the slot mixture have their own kernels here.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define BT_H 4
 #define BT_W 32
@@ -472,11 +473,121 @@ int bc_c4_bwd_data_launch(const float* dY, const float* Wb, const float* act, fl
     OCRL_CHECK_LAUNCH("bc_c4_bwd_data");
     return 0;
 }
+// The same weight gradient on the matrix cores (round 3): re-indexed over the INPUT pixel, dW[co][ci][ky][kx] = sum_p X[p][ci] *
+// dY[p - (ky-1, kx-1)][co] (dY zero outside the image), so an X tile needs no halo and every input element is read exactly once; the
+// 36 (tap, co) pairs are the rows of three 16-row MFMA blocks, the 64 input channels four 16-column blocks, pixels the k dimension
+// (v_mfma_f32_16x16x4_f32: a lane supplies dY of one (tap, co) at one of four pixels, and X of one channel at that pixel).  The VALU
+// form above spends 6144 issue cycles per 128-pixel tile on dependent LDS reads and FMAs at two waves per SIMD (0.75 TB/s);
+// this one 96 MFMAs per wave and tile.
+__global__ __launch_bounds__(256, 4) void bc_c4_wgrad_mfma_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ part, int Bn, int S) {
+    constexpr int HW_ = BT_W + 2, HH_ = BT_H + 2, NPX = BT_H * BT_W, LDXS = 65;        // X tile [pixel][64 + 1]
+    __shared__ float xs[NPX * LDXS];
+    __shared__ __attribute__((aligned(16))) float dh[HH_ * HW_ * 4];                 // dY halo [hy][hx][4]
+    const int tiles_x = (S + BT_W - 1) / BT_W, tiles_y = (S + BT_H - 1) / BT_H;
+    const int ntiles = tiles_x * tiles_y * Bn;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // per M block: this lane's (tap, co) row and its offset inside the dY halo relative to the pixel's (ly, lx)
+    int aoff[3]; bool aval[3];
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        const int i = mb * 16 + r16, tap = i >> 2, co = i & 3, ky = tap / 3, kx = tap - ky * 3;
+        aval[mb] = i < 36;
+        aoff[mb] = aval[mb] ? ((2 - ky) * HW_ + (2 - kx)) * 4 + co : 0;
+    }
+    constexpr int NLD = NPX * 16 / 256;            // float4 of the X tile per thread
+    constexpr int NDH = (HH_ * HW_ + 255) / 256;
+    float4 xv[NLD], dv[NDH];
+    auto fetch = [&](int t) {
+        int q = t;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y; q /= tiles_y;
+        const long long b = q;
+        const int x0 = tx * BT_W, y0 = ty * BT_H;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256, c4 = idx & 15, pp = idx >> 4;
+            const int x = x0 + pp % BT_W, y = y0 + pp / BT_W;
+            xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x < S && y < S) xv[i] = *reinterpret_cast<const float4*>(X + ((b * S + y) * S + x) * 64 + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NDH; ++i) {
+            const int hp = threadIdx.x + i * 256;
+            const int x = x0 - 1 + hp % HW_, y = y0 - 1 + hp / HW_;
+            dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hp < HH_ * HW_ && x >= 0 && x < S && y >= 0 && y < S) dv[i] = *reinterpret_cast<const float4*>(dY + ((b * S + y) * S + x) * 4);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = threadIdx.x + i * 256, c = (idx & 15) * 4, pp = idx >> 4;
+            xs[pp * LDXS + c] = xv[i].x; xs[pp * LDXS + c + 1] = xv[i].y; xs[pp * LDXS + c + 2] = xv[i].z; xs[pp * LDXS + c + 3] = xv[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NDH; ++i) {
+            const int hp = threadIdx.x + i * 256;
+            if (hp < HH_ * HW_) *reinterpret_cast<float4*>(dh + hp * 4) = dv[i];
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+        // this wave's 32 pixels (one tile row), four at a time
+#pragma unroll
+        for (int s = 0; s < BT_W / 4; ++s) {
+            const int lx = s * 4 + g, pp = wave * BT_W + lx;
+            const float* dp = dh + (wave * HW_ + lx) * 4;
+            float av[3], bv[4];
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb) av[mb] = aval[mb] ? dp[aoff[mb]] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bv[nb] = xs[pp * LDXS + nb * 16 + r16];
+#pragma unroll
+            for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+        }
+    }
+    // ---- sum the four waves' accumulators in a fixed order and write this block's partial [co][ci][tap]
+    __syncthreads();
+    float* red = xs;                               // [4 waves][16 rows][64 cols], one M block at a time
+    static_assert(4 * 16 * 64 <= NPX * LDXS, "reduction scratch must fit the X tile region");
+#pragma unroll
+    for (int mb = 0; mb < 3; ++mb) {
+        if (mb) __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * g + r) * 64 + nb * 16 + r16] = acc[mb][nb][r];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int row = e >> 6, ci = e & 63, i = mb * 16 + row;
+            if (i < 36) {
+                const float v = ((red[(0 * 16 + row) * 64 + ci] + red[(1 * 16 + row) * 64 + ci]) + red[(2 * 16 + row) * 64 + ci]) + red[(3 * 16 + row) * 64 + ci];
+                part[(size_t)blockIdx.x * 4 * 64 * 9 + ((i & 3) * 64 + ci) * 9 + (i >> 2)] = v;
+            }
+        }
+    }
+}
+
 int bc_c4_wgrad_blocks(int Bn, int S) {
     const int nt = cdiv(S, BT_W) * cdiv(S, BT_H) * Bn;
-    return nt < 512 ? nt : 512;
+    return nt < 1024 ? nt : 1024;
 }
 int bc_c4_wgrad_launch(const float* X, const float* dY, float* part, int Bn, int S, hipStream_t st) {
+    static int form = -1;
+    if (form < 0) { const char* e = getenv("OCRL_BC_WGRAD"); form = e ? atoi(e) : 2; }       // 1: the VALU form
+    if (form != 1) {
+        hipLaunchKernelGGL(bc_c4_wgrad_mfma_kernel, dim3(bc_c4_wgrad_blocks(Bn, S)), dim3(256), 0, st, X, dY, part, Bn, S);
+        OCRL_CHECK_LAUNCH("bc_c4_wgrad_mfma");
+        return 0;
+    }
     const int smem = ((BT_H + 2) * (BT_W + 2) * 64 + 128 * 4) * 4;
     static bool set = false;
     if (!set) { OCRL_HIP(hipFuncSetAttribute((const void*)bc_c4_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); set = true; }
