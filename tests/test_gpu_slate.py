@@ -455,17 +455,17 @@ def test_execution_switches_agree(monkeypatch):
     obs = torch.rand(B, 3, cfg.obs_size, cfg.obs_size, generator=torch.Generator().manual_seed(3)).cuda()
     noise = dev_noise(cfg, O.make_noise(cfg, B, 9))
 
+    base = {"OCRL_DW_SIDE": "2", "OCRL_XATTN": "1", "OCRL_CONV_X3": "0"}       # the default build, whatever the session's environment says
+
     def run(env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        for k, v in {**base, **env}.items():
+            monkeypatch.setenv(k, v)          # restored by the fixture when the test ends
         eng = make_engine(cfg, B)
         load_params(eng, P)
         for _ in range(2):
             eng.forward(obs, 0.9, train=True, seed=5, noise=noise)
             eng.backward()
         torch.cuda.synchronize()
-        for k in env:
-            monkeypatch.delenv(k)
         return eng.metrics.cpu().clone(), eng.flat_g.cpu().clone()
 
     m0, g0 = run({})
