@@ -243,6 +243,113 @@ __global__ __launch_bounds__(256) void layernorm_bwd64_kernel(const float* __res
     }
 }
 
+// 192-wide rows (the transformer decoder's d_model): the one-wave-per-row kernels keep one row of 4-byte loads in flight per wave and
+// need every wave slot of the machine to reach HBM speed -- alone they do (4.7-5.3 TB/s), but on the step's main stream they share the
+// CUs with the weight-gradient and dVAE streams and ran 2-4x longer (layernorm_bwd 243 vs 64 us, 13 launches per step on the critical
+// path).  Here 16 lanes own a row (three float4 each), a wave works on 4 rows per pass and keeps 2 passes (8 rows, 6 KB) in flight.
+__global__ __launch_bounds__(256) void layernorm_fwd192_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
+                                                               float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, long long R) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4 = lane & 15, rsub = lane >> 4;
+    const long long row0 = ((long long)blockIdx.x * 4 + wv) * 8 + rsub;
+    float4 v[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const long long row = row0 + 4 * i;
+            v[i][k] = row < R ? *reinterpret_cast<const float4*>(x + row * 192 + (k * 16 + c4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    float4 gg[3], bb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gg[k] = *reinterpret_cast<const float4*>(g + (k * 16 + c4) * 4); bb[k] = *reinterpret_cast<const float4*>(bta + (k * 16 + c4) * 4); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long row = row0 + 4 * i;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s += (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w);
+        const float mu = group16_sum(s) * (1.0f / 192);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[i][k].x -= mu; v[i][k].y -= mu; v[i][k].z -= mu; v[i][k].w -= mu;
+            q += (v[i][k].x * v[i][k].x + v[i][k].y * v[i][k].y) + (v[i][k].z * v[i][k].z + v[i][k].w * v[i][k].w);
+        }
+        const float rs = rsqrtf(group16_sum(q) * (1.0f / 192) + 1e-5f);
+        if (row < R) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                *reinterpret_cast<float4*>(y + row * 192 + (k * 16 + c4) * 4) = make_float4(v[i][k].x * rs * gg[k].x + bb[k].x, v[i][k].y * rs * gg[k].y + bb[k].y,
+                                                                                            v[i][k].z * rs * gg[k].z + bb[k].z, v[i][k].w * rs * gg[k].w + bb[k].w);
+            if (c4 == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_bwd192_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ g, float* __restrict__ dx,
+                                                               float* __restrict__ part, long long R, int accumulate) {
+    __shared__ float4 red[2][16][48];            // [dgamma | dbeta][wave * 4 + row group][float4 column]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c4 = lane & 15, rsub = lane >> 4;
+    float4 gg[3], dg[3], db[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { gg[k] = *reinterpret_cast<const float4*>(g + (k * 16 + c4) * 4); dg[k] = make_float4(0.f, 0.f, 0.f, 0.f); db[k] = dg[k]; }
+    for (long long grp = blockIdx.x; grp * 32 < R; grp += gridDim.x) {         // 32 rows per workgroup and pass
+        const long long row0 = (grp * 4 + wv) * 8 + rsub;
+        float4 xv[2][3], yv[2][3];
+        float mu[2], rs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long row = row0 + 4 * i;
+            const bool ok = row < R;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                xv[i][k] = ok ? *reinterpret_cast<const float4*>(x + row * 192 + (k * 16 + c4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                yv[i][k] = ok ? *reinterpret_cast<const float4*>(dy + row * 192 + (k * 16 + c4) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            mu[i] = ok ? mean[row] : 0.f;
+            rs[i] = ok ? rstd[row] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long row = row0 + 4 * i;
+            float4 xh[3], d4[3];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                xh[k] = make_float4((xv[i][k].x - mu[i]) * rs[i], (xv[i][k].y - mu[i]) * rs[i], (xv[i][k].z - mu[i]) * rs[i], (xv[i][k].w - mu[i]) * rs[i]);
+                const float4 yy = yv[i][k];
+                dg[k].x += yy.x * xh[k].x; dg[k].y += yy.y * xh[k].y; dg[k].z += yy.z * xh[k].z; dg[k].w += yy.w * xh[k].w;
+                db[k].x += yy.x; db[k].y += yy.y; db[k].z += yy.z; db[k].w += yy.w;
+                d4[k] = make_float4(yy.x * gg[k].x, yy.y * gg[k].y, yy.z * gg[k].z, yy.w * gg[k].w);
+                s1 += (d4[k].x + d4[k].y) + (d4[k].z + d4[k].w);
+                s2 += (d4[k].x * xh[k].x + d4[k].y * xh[k].y) + (d4[k].z * xh[k].z + d4[k].w * xh[k].w);
+            }
+            s1 = group16_sum(s1) * (1.0f / 192);
+            s2 = group16_sum(s2) * (1.0f / 192);
+            if (row < R) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float4 o = make_float4(rs[i] * (d4[k].x - s1 - xh[k].x * s2), rs[i] * (d4[k].y - s1 - xh[k].y * s2), rs[i] * (d4[k].z - s1 - xh[k].z * s2),
+                                           rs[i] * (d4[k].w - s1 - xh[k].w * s2));
+                    float* dp = dx + row * 192 + (k * 16 + c4) * 4;
+                    if (accumulate) { const float4 a = *reinterpret_cast<const float4*>(dp); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+                    *reinterpret_cast<float4*>(dp) = o;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { red[0][wv * 4 + rsub][k * 16 + c4] = dg[k]; red[1][wv * 4 + rsub][k * 16 + c4] = db[k]; }
+    __syncthreads();
+    if (threadIdx.x < 96) {                      // fixed order over the 16 (wave, row group) partials
+        const int which = threadIdx.x / 48, c = threadIdx.x % 48;
+        float4 a = red[which][0][c];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 t = red[which][k][c]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 384 + which * 192 + c * 4) = a;
+    }
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients etc.)
 // part[chunk][F] = sum over the chunk's rows of X[r][f]
 __global__ void colsum_kernel(const float* __restrict__ X, long long ld, float* __restrict__ part, long long R, int F, long long rows_per_chunk) {
@@ -1338,7 +1445,10 @@ int layernorm_fwd_launch(const float* x, const float* g, const float* b, float* 
             else hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, blk, 0, st, x, g, b, y, mean, rstd, R);
             break;
         case 2: hipLaunchKernelGGL(layernorm_fwd_kernel<2>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
-        case 3: hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
+        case 3:
+            if (al16) hipLaunchKernelGGL(layernorm_fwd192_kernel, dim3((unsigned)cdiv(R, 32)), blk, 0, st, x, g, b, y, mean, rstd, R);
+            else hipLaunchKernelGGL(layernorm_fwd_kernel<3>, grid, blk, 0, st, x, g, b, y, mean, rstd, R);
+            break;
         default: hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, blk, 0, st, x, g, b, y, mean, rstd, R); break;
     }
     OCRL_CHECK_LAUNCH("layernorm_fwd");
@@ -1388,7 +1498,11 @@ int layernorm_bwd_launch(const float* dy, const float* x, const float* mean, con
             else hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx);
             break;
         case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
-        case 3: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
+        case 3:
+            if (((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)g) & 15) == 0) && (((uintptr_t)ws) & 15) == 0)
+                hipLaunchKernelGGL(layernorm_bwd192_kernel, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx);
+            else hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx);
+            break;
         default: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, blk, 0, st, dy, x, mean, rstd, g, dx, ws, R, accumulate_dx); break;
     }
     OCRL_CHECK_LAUNCH("layernorm_bwd");
