@@ -398,16 +398,20 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
         *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * F + threadIdx.x * 4) = t;
     }
 }
-// out[c] (+)= scale * sum_k part[k][c]: 64 columns x 16 partial-row lanes per block (the partials are read in
-// parallel, not as one serial chain per column)
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int F, int accumulate, float scale) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (c < F)
-        for (int k = rl; k < nchunk; k += 16) s += part[(size_t)k * F + c];
-    red[rl][cl] = s;
+// out[c] (+)= scale * sum_k part[k][c]: 16 columns x 16 partial-row lanes per 256-thread block (the partials are read in parallel, not
+// as one serial chain per column; a 1024-thread block of 64 columns needed sixteen free wave slots on one CU and waited for them 3x its
+// own run time when other streams' kernels held the machine)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nchunk, int F, int accumulate, float scale) {
+    __shared__ float red[16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < F) {
+        int k = rl;
+        for (; k + 16 < nchunk; k += 32) { s0 += part[(size_t)k * F + c]; s1 += part[(size_t)(k + 16) * F + c]; }
+        if (k < nchunk) s0 += part[(size_t)k * F + c];
+    }
+    red[rl][cl] = s0 + s1;
     __syncthreads();
     if (rl == 0 && c < F) {
         float t = 0.f;
@@ -735,32 +739,52 @@ __global__ __launch_bounds__(256) void rowdot_bias64_kernel(const float* __restr
 
 // ------------------------------------------------------------------ token embedding (+BOS, +pos, dropout)
 // out[b,t,:] = drop( (t==0 ? bos : dict[tok[b,t-1]]) + pe[t] ),  dropout index over the reference's [B,T+1,d] tensor
-__global__ void embed_fwd_kernel(const int* __restrict__ tokens, const float* __restrict__ dict, const float* __restrict__ bos,
-                                 const float* __restrict__ pe, float* __restrict__ out, int B, int T, int d, float p,
-                                 unsigned long long seed) {
+// four rows of the same column group per thread: the token ids, then the four dictionary rows, are in flight together (the gather is two
+// dependent round trips; with one element per thread the kernel ran 7x longer beside other streams' kernels than alone)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ tokens, const float* __restrict__ dict, const float* __restrict__ bos,
+                                                        const float* __restrict__ pe, float* __restrict__ out, int B, int T, int d, float p,
+                                                        unsigned long long seed) {
     const int d4 = d / 4;
     const long long n = (long long)B * T * d4;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c4 = i % d4;
-    const long long bt = i / d4;
-    const int t = bt % T;
-    const long long b = bt / T;
-    const float* src = t == 0 ? bos : dict + (size_t)tokens[b * T + t - 1] * d;
-    float4 v = *reinterpret_cast<const float4*>(src + c4 * 4);
-    const float4 pv = *reinterpret_cast<const float4*>(pe + (size_t)t * d + c4 * 4);
-    v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
-    if (p > 0.f) {
-        const uint64_t idx4 = ((uint64_t)(b * (T + 1) + t) * d) / 4 + c4;
-        const uint2 bits = rng_bits4(seed, SITE_ZPOS, idx4);
-        const uint32_t thr = drop_thresh(p);
-        const float sc = 1.0f / (1.0f - p);
-        v.x = rng_keep(bits, 0, thr) ? v.x * sc : 0.f;
-        v.y = rng_keep(bits, 1, thr) ? v.y * sc : 0.f;
-        v.z = rng_keep(bits, 2, thr) ? v.z * sc : 0.f;
-        v.w = rng_keep(bits, 3, thr) ? v.w * sc : 0.f;
+    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t thr = drop_thresh(p);
+    const float sc = 1.0f / (1.0f - p);
+    int tok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + k * 256, bt = i / d4;
+        const int t = (int)(bt % T);
+        tok[k] = (i < n && t > 0) ? tokens[bt - 1] : -1;          // row (b, t) embeds token (b, t - 1); bt - 1 = b * T + t - 1
     }
-    *reinterpret_cast<float4*>(out + i * 4) = v;
+    float4 v[4], pv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + k * 256, bt = i / d4;
+        const int c4 = (int)(i % d4), t = (int)(bt % T);
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f); pv[k] = v[k];
+        if (i < n) {
+            v[k] = *reinterpret_cast<const float4*>((tok[k] < 0 ? bos : dict + (size_t)tok[k] * d) + c4 * 4);
+            pv[k] = *reinterpret_cast<const float4*>(pe + (size_t)t * d + c4 * 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + k * 256;
+        if (i >= n) continue;
+        const long long bt = i / d4;
+        const int c4 = (int)(i % d4), t = (int)(bt % T);
+        const long long b = bt / T;
+        float4 o = make_float4(v[k].x + pv[k].x, v[k].y + pv[k].y, v[k].z + pv[k].z, v[k].w + pv[k].w);
+        if (p > 0.f) {
+            const uint64_t idx4 = ((uint64_t)(b * (T + 1) + t) * d) / 4 + c4;
+            const uint2 bits = rng_bits4(seed, SITE_ZPOS, idx4);
+            o.x = rng_keep(bits, 0, thr) ? o.x * sc : 0.f;
+            o.y = rng_keep(bits, 1, thr) ? o.y * sc : 0.f;
+            o.z = rng_keep(bits, 2, thr) ? o.z * sc : 0.f;
+            o.w = rng_keep(bits, 3, thr) ? o.w * sc : 0.f;
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = o;
+    }
 }
 
 // ---- gradient of the token dictionary: ddict[tok] = sum of the rows of g whose input token is tok (slate_module.py:141-146: row (b, t)
@@ -1472,7 +1496,7 @@ int colsum_launch(const float* X, long long ld, float* out, long long R, int F, 
             nchunk = (R + rpc - 1) / rpc;
             hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)nchunk), dim3(256), 0, st, X, ld, ws, R, F, rpc);
             OCRL_CHECK_LAUNCH("colsum4");
-            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 64)), dim3(1024), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 16)), dim3(256), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
             OCRL_CHECK_LAUNCH("colsum_final");
             return 0;
         }
@@ -1486,7 +1510,7 @@ int colsum_launch(const float* X, long long ld, float* out, long long R, int F, 
     const long long rpc = (R + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(colsum_kernel, dim3(cb, (int)nchunk), dim3(256), 0, st, X, ld, ws, R, F, rpc);
     OCRL_CHECK_LAUNCH("colsum");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 64)), dim3(1024), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(F, 16)), dim3(256), 0, st, ws, out, (int)nchunk, F, accumulate, scale);
     OCRL_CHECK_LAUNCH("colsum_final");
     return 0;
 }
@@ -1589,7 +1613,7 @@ int embed_fwd_launch(const int* tokens, const float* dict, const float* bos, con
                      unsigned long long seed, hipStream_t st) {
     OCRL_REQUIRE(d % 4 == 0, "embed: d %% 4 != 0");
     const long long n = (long long)B * T * (d / 4);
-    hipLaunchKernelGGL(embed_fwd_kernel, GRID1D(n), 0, st, tokens, dict, bos, pe, out, B, T, d, p, seed);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)cdiv(n, 1024)), dim3(256), 0, st, tokens, dict, bos, pe, out, B, T, d, p, seed);
     OCRL_CHECK_LAUNCH("embed_fwd");
     return 0;
 }
