@@ -929,27 +929,19 @@ __global__ void embed_drop_bwd_kernel(float* __restrict__ g, int B, int T, int d
 }
 
 // y = x * keep/(1-p) for the dropout site (n % 4 == 0); index = element offset
-// four float4 per thread in flight (it runs on the step's main stream beside other streams' kernels: with one load per thread it
-// depended on every wave slot of the machine)
-__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p,
-                                                            unsigned long long seed, unsigned site) {
-    const long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+__global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, long long n4, float p,
+                                     unsigned long long seed, unsigned site) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    const uint2 bits = rng_bits4(seed, site, (uint64_t)i);
     const uint32_t thr = drop_thresh(p);
     const float sc = 1.0f / (1.0f - p);
-    float4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const long long i = i0 + k * 256; v[k] = i < n4 ? *reinterpret_cast<const float4*>(x + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const long long i = i0 + k * 256;
-        if (i >= n4) continue;
-        const uint2 bits = rng_bits4(seed, site, (uint64_t)i);
-        v[k].x = rng_keep(bits, 0, thr) ? v[k].x * sc : 0.f;
-        v[k].y = rng_keep(bits, 1, thr) ? v[k].y * sc : 0.f;
-        v[k].z = rng_keep(bits, 2, thr) ? v[k].z * sc : 0.f;
-        v[k].w = rng_keep(bits, 3, thr) ? v[k].w * sc : 0.f;
-        *reinterpret_cast<float4*>(y + i * 4) = v[k];
-    }
+    v.x = rng_keep(bits, 0, thr) ? v.x * sc : 0.f;
+    v.y = rng_keep(bits, 1, thr) ? v.y * sc : 0.f;
+    v.z = rng_keep(bits, 2, thr) ? v.z * sc : 0.f;
+    v.w = rng_keep(bits, 3, thr) ? v.w * sc : 0.f;
+    *reinterpret_cast<float4*>(y + i * 4) = v;
 }
 // keep-mask dump (float 0/1) for the parity tests: exactly the decisions the kernels take
 __global__ void dropout_mask_kernel(float* __restrict__ y, long long n, float p, unsigned long long seed, unsigned site) {
@@ -1518,7 +1510,7 @@ int layernorm_bwd_launch(const float* dy, const float* x, const float* mean, con
                          float* dgb, long long R, int F, int accumulate_dx, int accumulate_dgb, float* ws, size_t ws_floats, hipStream_t st) {
     OCRL_REQUIRE(F % 64 == 0 && F >= 64 && F <= 256, "layernorm bwd: F must be 64..256, multiple of 64 (got %d)", F);
     int nblk = (int)((R + 3) / 4);
-    if (nblk > 2048) nblk = 2048;         // 8 waves per SIMD: the kernel is latency-bound (one row per wave and iteration)
+    if (nblk > 2048) nblk = 2048;         // 8 waves per SIMD (1024 / 4096 workgroups measured the same in the step)
     while (nblk > 64 && (size_t)nblk * 2 * F * 2 + (size_t)8 * 2 * F > ws_floats) nblk /= 2;
     const size_t need = (size_t)nblk * 2 * F;
     OCRL_REQUIRE(need + (size_t)8 * 2 * F <= ws_floats, "layernorm bwd: workspace too small");
@@ -1651,7 +1643,7 @@ int embed_bwd_launch(float* g, const int* tokens, float* ddict, int B, int T, in
 }
 int dropout_apply_launch(const float* x, float* y, long long n, float p, unsigned long long seed, unsigned site, hipStream_t st) {
     OCRL_REQUIRE(n % 4 == 0, "dropout_apply: n %% 4 != 0");
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)cdiv(n / 4, 1024)), dim3(256), 0, st, x, y, n / 4, p, seed, site);
+    hipLaunchKernelGGL(dropout_apply_kernel, GRID1D(n / 4), 0, st, x, y, n / 4, p, seed, site);
     OCRL_CHECK_LAUNCH("dropout_apply");
     return 0;
 }
