@@ -1,18 +1,19 @@
 // EXPLORATORY (OCRL_CONV_X3=1, never the default, never the headline bench line): the 5x5 and 3x3 / 64-channel convolutions (forward,
 // backward data, weight gradient) on the bf16 matrix pipe with fp32-equivalent split precision.  gfx950 has no xf32 / tf32 MFMA and the fp32 MFMA runs at 1/16 of the bf16 rate, so the
 // fp32 convolutions (0.87 of that peak) cannot get faster on it.  Here every fp32 operand is written as the EXACT sum of three bf16
-// numbers, x = h + m + l (h = the top 8 significant bits by truncation, m the next 8, l the last 8: both subtractions are exact in
-// fp32), and x*w is accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 products
+// numbers, x = h + m + l (h = bf16(x) rounded to nearest, m = bf16(x - h), l = x - h - m: both subtractions are exact in fp32 and l fits
+// bf16), and x*w is accumulated in fp32 from six v_mfma_f32_32x32x16_bf16 products
 //      h*h' + h*m' + m*h' + m*m' + h*l' + l*h'
-// -- the three dropped terms (m*l', l*m', l*l') are below 2^-24 of |x*w|, the rounding of an fp32 product.  Six bf16 products of 16 k
+// -- the three dropped terms (m*l', l*m', l*l') are each below 2^-24 of |x*w| (|m| <= 2^-8 |x|, |l| <= 2^-16 |x|), the rounding of one fp32
+// product; against fp64 the results measure the same as the fp32-MFMA kernels'.  Six bf16 products of 16 k
 // each cost 6 x 32 cycles for what eight fp32 32x32x2 products need 8 x 64 cycles for: 2.67x fewer matrix-pipe cycles.
 //
 // Kernel shape: 8 rows x 32 pixels per workgroup, a wave owns two rows (two 32-pixel M blocks) x 64 output channels, so one weight
 // fragment feeds two MFMAs per product and the packed weights (three bf16 planes, [tap][chunk][n-block][plane][lane][8]) can stream
 // from L2 at 32 B/clk/CU.  The halo stays fp32 in LDS, 32 input channels at a time (two phases per tile, 62 KB, two workgroups per
 // CU; the first version held all 64 channels, 117.5 KB, one workgroup per CU: 2.05 ms per launch at B = 128 / 128x128), and an A
-// fragment (8 channels of a pixel) is split into its three bf16 planes in registers right before its MFMAs (bit masks, two exact
-// subtractions and three v_perm_b32 per pair of values, issued in the shadow of the MFMAs).  Same epilogue features as
+// fragment (8 channels of a pixel) is split into its three bf16 planes in registers right before its MFMAs (three v_cvt_pk_bf16_f32, two
+// shifts / masks and four exact subtractions per pair of values, issued in the shadow of the MFMAs).  Same epilogue features as
 // conv_fwd_kernel (bias, ReLU / ELU, position map, activation mask), so it also serves the backward-data pass.
 #include "common.h"
 #include "kernels.h"
@@ -24,21 +25,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define X3_TW 32
 #define X3_NCH 4          // 16-channel chunks of the 64 input channels
 
-__device__ __forceinline__ uint32_t x3_hi(float x) { return __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u; }
-// eight fp32 values (two float4) -> three planes of eight bf16 (h, m, l), x = h + m + l exactly
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two fp32 values -> their bf16 roundings (round to nearest even: v_cvt_pk_bf16_f32), packed {hi16 = b, lo16 = a}
+__device__ __forceinline__ uint32_t x3_pk(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float x3_lo(uint32_t pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float x3_up(uint32_t pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
+// eight fp32 values (two float4) -> three planes of eight bf16 (h, m, l), x = h + m + l exactly: h = bf16(x), m = bf16(x - h), l = x - h - m
+// (both subtractions are exact in fp32 and l has at most 8 significant bits, so it is a bf16 number).  Rounding to nearest instead of
+// truncating halves |m| and |l|: |m| <= 2^-8 |x|, |l| <= 2^-16 |x|, the dropped products m*l', l*m' are below 2^-24 of |x*w|.
 __device__ __forceinline__ void x3_split(const float4& a, const float4& b, uint4& h, uint4& m, uint4& l) {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float x0 = x[2 * p], x1 = x[2 * p + 1];
-        const uint32_t h0 = x3_hi(x0), h1 = x3_hi(x1);
-        ph[p] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);                       // {h1.hi16, h0.hi16}
-        const float r0 = x0 - __builtin_bit_cast(float, h0), r1 = x1 - __builtin_bit_cast(float, h1);
-        const uint32_t m0 = x3_hi(r0), m1 = x3_hi(r1);
-        pm[p] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-        const float q0 = r0 - __builtin_bit_cast(float, m0), q1 = r1 - __builtin_bit_cast(float, m1);
-        pl[p] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, q1), __builtin_bit_cast(uint32_t, q0), 0x07060302u);
+        ph[p] = x3_pk(x0, x1);
+        const float r0 = x0 - x3_lo(ph[p]), r1 = x1 - x3_up(ph[p]);
+        pm[p] = x3_pk(r0, r1);
+        pl[p] = x3_pk(r0 - x3_lo(pm[p]), r1 - x3_up(pm[p]));
     }
     h = make_uint4(ph[0], ph[1], ph[2], ph[3]); m = make_uint4(pm[0], pm[1], pm[2], pm[3]); l = make_uint4(pl[0], pl[1], pl[2], pl[3]);
 }
@@ -258,10 +266,11 @@ __global__ void conv_pack_x3_kernel(const float* __restrict__ W, uint4* __restri
 // transposed X tile: rows of HW = 32 + KS - 1 pixels stored at a stride of HWP (a multiple of 4, so every fragment read is 16-byte
 // aligned), LDX floats per ci row (+4: conflict-free reads)
 template <int KS> struct WxGeo { static constexpr int HW = WX_TW + KS - 1, HWP = (HW + 3) & ~3, NPX = WX_TH * HWP, LDX = NPX + 4, NV = KS + 7; };
+// one value -> its three planes, each as an fp32 bit pattern with the low 16 bits clear (packed into pairs by X3_PK)
 __device__ __forceinline__ void x3_planes(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = x3_hi(v);
+    h = __builtin_bit_cast(uint32_t, (float)(__bf16)v);
     const float r = v - __builtin_bit_cast(float, h);
-    m = x3_hi(r);
+    m = __builtin_bit_cast(uint32_t, (float)(__bf16)r);
     l = __builtin_bit_cast(uint32_t, r - __builtin_bit_cast(float, m));
 }
 #define X3_PK(hi_, lo_) __builtin_amdgcn_perm((hi_), (lo_), 0x07060302u)
